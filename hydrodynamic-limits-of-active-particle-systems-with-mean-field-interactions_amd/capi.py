@@ -1,0 +1,228 @@
+"""ctypes binding of libaps_hip.so (the C ABI declared in include/aps.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is present the constructor of
+`Handle` raises.  Loading the library itself works without a GPU (used by the CPU test that checks
+the exported symbols against the header)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libaps_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "aps.h")
+
+APS_OK, APS_ERR_ARG, APS_ERR_HIP, APS_ERR_STATE, APS_ERR_NODEVICE = 0, -1, -2, -3, -4
+
+
+class ApsError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libaps_hip error {code}: {text}")
+        self.code = code
+
+
+class ApsParams(C.Structure):
+    """struct aps_params of include/aps.h, field for field."""
+    _fields_ = [
+        ("L", C.c_int32), ("K", C.c_int32), ("periodic", C.c_int32), ("minus_anchor", C.c_int32),
+        ("immobilize", C.c_int32), ("suppress_flip", C.c_int32), ("crowding", C.c_int32),
+        ("n_ensembles", C.c_int32), ("n_particles", C.c_int64), ("sigma_grid", C.c_double),
+        ("rate_diffusion", C.c_double), ("rate_active", C.c_double), ("k_on", C.c_double),
+        ("k_off", C.c_double), ("k_exit", C.c_double), ("dt", C.c_double), ("seed", C.c_uint64),
+        ("beta", C.POINTER(C.c_double)), ("anchor_mask", C.POINTER(C.c_uint8)), ("device", C.c_int32),
+        ("rank", C.c_int32), ("world", C.c_int32), ("sort_by_site", C.c_int32),
+        ("ensemble_base", C.c_int32), ("reserved", C.c_int32 * 3),
+    ]
+
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/aps.h."""
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r"\b(aps_[a-z_0-9]+)\s*\(", text)))
+
+
+def load():
+    """dlopen the library (no GPU needed for this) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python {os.path.join(HERE, 'build.py')}` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    P = C.POINTER
+    protos = {
+        "aps_device_count": (C.c_int, []),
+        "aps_last_error": (C.c_char_p, [vp]),
+        "aps_create": (C.c_int, [P(ApsParams), P(vp)]),
+        "aps_destroy": (None, [vp]),
+        "aps_set_stream": (C.c_int, [vp, vp]),
+        "aps_set_state": (C.c_int, [vp, i32, vp, vp, vp, vp, i64]),
+        "aps_get_state": (C.c_int, [vp, i32, vp, vp, vp, vp, i64]),
+        "aps_pair_accumulate": (C.c_int, [vp, i32, vp, vp, vp, i64]),
+        "aps_step": (C.c_int, [vp, i64]),
+        "aps_propose": (C.c_int, [vp]),
+        "aps_commit": (C.c_int, [vp]),
+        "aps_exchange_buffer": (C.c_int, [vp, P(vp), P(i64), P(i64), P(i64)]),
+        "aps_bind_exchange_buffer": (C.c_int, [vp, vp, i64]),
+        "aps_observe": (C.c_int, [vp, i32, vp, vp, vp]),
+        "aps_field_from_counts": (C.c_int, [vp, i32, vp, vp, vp]),
+        "aps_time": (C.c_int, [vp, P(dbl), P(i64)]),
+        "aps_get_exits": (C.c_int, [vp, i32, vp, i64, P(i64)]),
+        "aps_get_table": (C.c_int, [vp, vp, i32, P(i32), P(i32)]),
+        "aps_resort": (C.c_int, [vp]),
+        "aps_step_timed": (C.c_int, [vp, i64, P(dbl), P(i64), P(dbl)]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    lib._aps_protos = protos
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+    """One aps_handle: E ensembles of n particles on one GPU (optionally one shard of a multi-GPU job)."""
+
+    def __init__(self, *, L, K, periodic, sigma_grid, rate_diffusion, rate_active, beta, dt, seed,
+                 n_particles, minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False,
+                 k_on=0.0, k_off=0.0, k_exit=0.0, anchor_mask=None, device=0, rank=0, world=1,
+                 sort_by_site=True, ensemble_base=0):
+        self.lib = load()
+        self._h = C.c_void_p()
+        betas = np.atleast_1d(np.asarray(beta, dtype=np.float64)).copy()
+        self.E, self.n, self.L, self.K = len(betas), int(n_particles), int(L), int(K)
+        self.dt = float(dt)
+        mask = None if anchor_mask is None else np.ascontiguousarray(anchor_mask, dtype=np.uint8)
+        if mask is not None and not mask.any():
+            mask = None
+        par = ApsParams(L=L, K=K, periodic=int(bool(periodic)), minus_anchor=int(bool(minus_anchor)),
+                        immobilize=int(bool(immobilize)), suppress_flip=int(bool(suppress_flip)),
+                        crowding=int(bool(crowding)), n_ensembles=self.E, n_particles=self.n,
+                        sigma_grid=float(sigma_grid), rate_diffusion=float(rate_diffusion),
+                        rate_active=float(rate_active), k_on=float(k_on), k_off=float(k_off),
+                        k_exit=float(k_exit), dt=self.dt, seed=int(seed) & (2 ** 64 - 1),
+                        beta=betas.ctypes.data_as(C.POINTER(C.c_double)),
+                        anchor_mask=None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_uint8)),
+                        device=int(device), rank=int(rank), world=int(world),
+                        sort_by_site=int(bool(sort_by_site)), ensemble_base=int(ensemble_base))
+        rc = self.lib.aps_create(C.byref(par), C.byref(self._h))
+        if rc != APS_OK:
+            raise ApsError(rc, self.lib.aps_last_error(None).decode())
+
+    # -- plumbing
+    def _ck(self, rc):
+        if rc != APS_OK:
+            raise ApsError(rc, self.lib.aps_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.aps_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, raw_stream):
+        self._ck(self.lib.aps_set_stream(self._h, C.c_void_p(raw_stream)))
+
+    # -- state
+    def set_state(self, pos, sigma, bound=None, alive=None, ensemble=0):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        sigma = np.ascontiguousarray(sigma, dtype=np.int8)
+        bound = None if bound is None else np.ascontiguousarray(bound, dtype=np.uint8)
+        alive = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint8)
+        self._ck(self.lib.aps_set_state(self._h, ensemble, _ptr(pos), _ptr(sigma), _ptr(bound), _ptr(alive), len(pos)))
+        self._n_set = getattr(self, "_n_set", {})
+        self._n_set[ensemble] = len(pos)
+
+    def get_state(self, ensemble=0):
+        n = self._n_set[ensemble]
+        pos, sigma = np.zeros(n, np.int32), np.zeros(n, np.int8)
+        bound, alive = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        self._ck(self.lib.aps_get_state(self._h, ensemble, _ptr(pos), _ptr(sigma), _ptr(bound), _ptr(alive), n))
+        return pos, sigma, bound, alive
+
+    def pair_accumulate(self, ensemble=0):
+        n = self._n_set[ensemble]
+        S, W, occ4 = np.zeros(n), np.zeros(n), np.zeros((n, 4), np.int32)
+        self._ck(self.lib.aps_pair_accumulate(self._h, ensemble, _ptr(S), _ptr(W), _ptr(occ4), n))
+        return S, W, occ4
+
+    # -- stepping
+    def step(self, nsteps=1):
+        self._ck(self.lib.aps_step(self._h, int(nsteps)))
+
+    def propose(self):
+        self._ck(self.lib.aps_propose(self._h))
+
+    def commit(self):
+        self._ck(self.lib.aps_commit(self._h))
+
+    def exchange_buffer(self):
+        ptr, tot, off, mine = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.aps_exchange_buffer(self._h, C.byref(ptr), C.byref(tot), C.byref(off), C.byref(mine)))
+        return ptr.value, tot.value, off.value, mine.value
+
+    def bind_exchange_buffer(self, dev_ptr, nbytes):
+        self._ck(self.lib.aps_bind_exchange_buffer(self._h, C.c_void_p(dev_ptr), int(nbytes)))
+
+    def step_timed(self, nsteps):
+        ms, n, pairs = C.c_double(), C.c_int64(), C.c_double()
+        self._ck(self.lib.aps_step_timed(self._h, int(nsteps), C.byref(ms), C.byref(n), C.byref(pairs)))
+        return ms.value, n.value, pairs.value
+
+    # -- observation
+    def observe(self, ensemble=0, want_field=True):
+        cp, cm = np.zeros(self.L, np.int64), np.zeros(self.L, np.int64)
+        m = np.zeros(self.L) if want_field else None
+        self._ck(self.lib.aps_observe(self._h, ensemble, _ptr(cp), _ptr(cm), _ptr(m)))
+        return cp, cm, m
+
+    def field_from_counts(self, counts_p, counts_m, ensemble=0):
+        cp = np.ascontiguousarray(counts_p, dtype=np.int64)
+        cm = np.ascontiguousarray(counts_m, dtype=np.int64)
+        m = np.zeros(self.L)
+        self._ck(self.lib.aps_field_from_counts(self._h, ensemble, _ptr(cp), _ptr(cm), _ptr(m)))
+        return m
+
+    def time(self):
+        t, k = C.c_double(), C.c_int64()
+        self._ck(self.lib.aps_time(self._h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
+    def exits(self, ensemble=0):
+        n = C.c_int64()
+        self._ck(self.lib.aps_get_exits(self._h, ensemble, None, 0, C.byref(n)))
+        rows = np.zeros((max(n.value, 1), 3))
+        self._ck(self.lib.aps_get_exits(self._h, ensemble, _ptr(rows), len(rows), C.byref(n)))
+        return rows[:n.value]
+
+    def table(self):
+        tlen, q = C.c_int32(), C.c_int32()
+        self._ck(self.lib.aps_get_table(self._h, None, 0, C.byref(tlen), C.byref(q)))
+        out = np.zeros(max(tlen.value, 1))
+        self._ck(self.lib.aps_get_table(self._h, _ptr(out), len(out), C.byref(tlen), C.byref(q)))
+        return out[:tlen.value], q.value
+
+    def resort(self):
+        self._ck(self.lib.aps_resort(self._h))
+
+
+def device_count():
+    return load().aps_device_count()

@@ -1,0 +1,1080 @@
+// aps_hip.hip -- MI355X (gfx950) implementation of the C ABI in include/aps.h.
+//
+// Hot path replaced: ParticleSystem.run's loop body of the reference, i.e.
+//   compute_local_m_field (PARTICLE_solver_CLASS.py:216-246)  +  step_gillespie (:254-448),
+// restated as a fixed-dt synchronous stepper (DESIGN.md "The synchronous scheme").
+//
+// Per step three launches:
+//   pair_propose  all-pairs tile kernel: per target particle S = sum sigma_j w(d_ij), W = sum w(d_ij),
+//                 occupancy of the neighbouring sites; epilogue = rates -> Philox draw -> proposal byte
+//   claim         hop proposals register at their target site (tiny per-site lists)
+//   apply         index-ordered arbitration of the hops, state update, per-tile position bounds
+//
+// Data layout in HBM (one handle, E ensembles, Npad slots each, slot order = internal order):
+//   src  [E][Npad] u32   packed particle: bits 0-26 site, 27 spin(+), 28 bound, 29 dead
+//   orig [E][Npad] u32   original particle index of the slot (Philox counter, tie-break, output order)
+//   prop [world][E][SH] u8  proposals; rank r owns block r (exchanged between ranks once per step)
+//   bounds [E][Npad/64] int2  min/max live site per 64-slot tile (tile culling)
+//   pcnt [E][L] u32, plist [E][L][2K] u32   per-site proposer lists for the commit
+//
+// Arithmetic: binary64 throughout; the weight table lives on the grid 2^-q so every partial sum is
+// exact and the result does not depend on summation order (any tiling, any number of GPUs, CPU oracle).
+// Compile with -ffp-contract=off: the rate/probability code is a fixed sequence of IEEE operations.
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "aps.h"
+
+namespace {
+
+constexpr uint32_t POS_MASK = 0x07FFFFFFu;
+constexpr uint32_t SPIN_BIT = 1u << 27;
+constexpr uint32_t BOUND_BIT = 1u << 28;
+constexpr uint32_t DEAD_BIT = 1u << 29;
+constexpr uint32_t DEAD_P8 = POS_MASK << 3;   // far-away site (x8) every distance test rejects
+constexpr int TILE = 64;                      // slots per tile = one wavefront of targets
+constexpr int WAVES = 4;                      // waves per workgroup; they split the source tiles
+
+enum { EV_NONE = 0, EV_LEFT = 1, EV_RIGHT = 2, EV_FWD = 3, EV_BIND = 4, EV_UNBIND = 5, EV_EXIT = 6, EV_FLIP = 7 };
+
+// ---------------------------------------------------------------------------------------------
+// deterministic exp: mul, fma, rint and an exponent insert only -> identical bits on host and device
+__host__ __device__ inline double aps_exp(double x) {
+    const double LOG2E = 0x1.71547652b82fep+0, LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33;
+    x = x > 700.0 ? 700.0 : (x < -700.0 ? -700.0 : x);
+    const double kf = rint(x * LOG2E);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 0x1.6124613a86d09p-33;                       // 1/13!
+    p = fma(p, r, 0x1.1eed8eff8d898p-29);
+    p = fma(p, r, 0x1.ae64567f544e4p-26);
+    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma(p, r, 0x1.71de3a556c734p-19);
+    p = fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = fma(p, r, 0x1.1111111111111p-7);
+    p = fma(p, r, 0x1.5555555555555p-5);
+    p = fma(p, r, 0x1.5555555555555p-3);
+    p = fma(p, r, 0x1.0000000000000p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const long long k = (long long)kf, k1 = k / 2, k2 = k - k1;
+    union { unsigned long long u; double d; } s1, s2;
+    s1.u = (unsigned long long)(k1 + 1023) << 52;
+    s2.u = (unsigned long long)(k2 + 1023) << 52;
+    return p * s1.d * s2.d;
+}
+
+// Philox4x32-10 (Salmon et al., Random123): counter-based, so a particle's draw depends only on
+// (seed, step, particle index, ensemble) -- never on which thread, GPU or tiling evaluated it.
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                     uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Model {               // by-value kernel argument: everything the rate code needs
+    int L, K, periodic, field_mode, minus_anchor, immobilize, suppress_flip, crowding;
+    double rate_diffusion, rate_active, k_on, k_off, k_exit, dt;
+    uint32_t seed_lo, seed_hi;
+    int ens_base;
+};
+
+struct PairArgs {
+    Model m;
+    const uint32_t *orig;     // [E][Npad]
+    const long long *gsum;    // [E][2] sum of spins, number alive (global-field mode)
+    const double *beta;       // [E]
+    const uint8_t *anchor;    // [L] or nullptr
+    uint8_t *prop;            // [world][E][SH]
+    uint32_t *pcnt;           // [E][L], zeroed here for the commit that follows
+    double *S_out, *W_out;    // optional [E][Npad]
+    int *occ4_out;            // optional [E][Npad][4]
+    unsigned long long *tiles_done;   // statistics: source tiles actually evaluated
+    int tlen, Npad, SH, E, ntiles, tile_lo, tile_cnt;
+    uint32_t step_lo, step_hi;
+    int write_prop;
+};
+
+// |a - b| in one VALU op (the compiler expands __usad into min/max/sub).  b is wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t absdiff_vs(uint32_t a_vec, uint32_t b_uni) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a_vec), "s"(b_uni));
+    return d;
+}
+
+// One tile of 64 sources against this lane's target, in groups of 16.  The source words are
+// wave-uniform: they arrive by scalar loads (s_load_dwordx8/16) and are decoded on the scalar unit;
+// per pair the vector unit does |dp| (v_sad_u32), clamp, one LDS table read and two f64 accumulations.
+// Occupancy (same / neighbouring site) is rare, so the hot path only tracks the group's smallest
+// distance and the classification is redone under a per-group branch.
+template <int BC, bool MIRROR>
+__device__ __forceinline__ void tile_loop(const uint32_t *__restrict__ tile, const uint32_t pi8,
+                                          const double *__restrict__ tab, const uint32_t tlen8, const uint32_t L8,
+                                          double &accW, double &accS, int &c0, int &cl, int &cr) {
+    constexpr int G = 16;
+#pragma unroll 1
+    for (int g = 0; g < TILE; g += G) {
+        uint32_t w[G];
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tile + g);
+#pragma unroll
+        for (int k = 0; k < G / 4; ++k) {
+            const uint4 v = t4[k];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+        uint32_t near = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const uint32_t pj8 = (w[k] & DEAD_BIT) ? DEAD_P8 : ((w[k] & POS_MASK) << 3);
+            const double sg = (w[k] & SPIN_BIT) ? 1.0 : -1.0;
+            const uint32_t d8 = absdiff_vs(pi8, pj8);
+            uint32_t t8 = d8;
+            if (BC == 1) t8 = min(d8, L8 - d8);              // circular distance on the torus
+            double wt = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + min(t8, tlen8));
+            if (MIRROR) {                                    // reflected images: distance p_i + p_j + 1 (mod 2L)
+                const uint32_t s8 = pi8 + pj8 + 8u;
+                const uint32_t m8 = min(min(s8, 2u * L8 - s8), tlen8);
+                wt += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + m8);
+            }
+            accW += wt;
+            accS = fma(wt, sg, accS);
+            near = min(near, t8);
+        }
+        if (near <= 8u) {                                    // rare: same or neighbouring site -> occupancy
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if (w[k] & DEAD_BIT) continue;
+                const int dlt = (int)((w[k] & POS_MASK) << 3) - (int)pi8;
+                c0 += (dlt == 0);
+                cr += (dlt == 8) | (BC == 1 && dlt == 8 - (int)L8);
+                cl += (dlt == -8) | (BC == 1 && dlt == (int)L8 - 8);
+            }
+        }
+    }
+}
+
+// Does any (target in [tlo,thi], source in [slo,shi]) pair fall inside the table's reach R?
+template <int BC>
+__device__ __forceinline__ void tile_tests(int tlo, int thi, int slo, int shi, int R, int L, bool &direct, bool &mirror) {
+    if (BC == 0) {
+        direct = (slo <= thi + R) && (shi >= tlo - R);
+        mirror = (tlo + slo + 1 <= R) || (2 * L - 1 - thi - shi <= R);
+    } else {
+        mirror = false;
+        const int lo = slo - thi, hi = shi - tlo;            // range of p_j - p_i
+        direct = (hi - lo >= L) || (lo <= R && hi >= -R) || (lo - L <= R && hi - L >= -R) ||
+                 (lo + L <= R && hi + L >= -R);
+    }
+}
+
+struct Channels { double diff, act, flip, bind, unbind, leave, left, right, total; };
+
+// Rate table of one particle: the arithmetic of step_gillespie's vector section (ref :261-351),
+// operation for operation (same association order as the NumPy expressions).
+__device__ inline Channels channels(const Model &M, bool anchored_site, int p, int spin, bool bound, double mloc,
+                                    double beta, int occ_self, int occ_left, int occ_right) {
+    const int L = M.L, K = M.K;
+    const bool plus = spin > 0;
+    double flip = aps_exp(-beta * (double)spin * mloc);
+    if (M.suppress_flip && bound) flip = 0.0;
+    // target sites: forward = right neighbour for +, own site for -; walls clip, torus wraps
+    const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == L - 1;
+    const int o_l = wall_l ? occ_self : occ_left, o_r = wall_r ? occ_self : occ_right;
+    const int o_f = plus ? o_r : occ_self;
+    const bool open_l = !wall_l && o_l < K, open_r = !wall_r && o_r < K, open_f = plus && open_r;
+    double hl = M.rate_diffusion * (double)open_l, hr = M.rate_diffusion * (double)open_r;
+    double act = (plus || !M.minus_anchor) ? M.rate_active : 0.0;
+    double leave = 0.0;
+    const bool held = M.immobilize && !plus && anchored_site && bound;
+    if (held) { act = 0.0; hl = 0.0; hr = 0.0; leave = M.k_exit; }
+    double diff = hl + hr;
+    if (!(plus && open_f)) act = 0.0;
+    if (M.crowding) {
+        double ff = 1.0 - (double)o_f / (double)K, fl = 1.0 - (double)o_l / (double)K, fr = 1.0 - (double)o_r / (double)K;
+        ff = ff < 0.0 ? 0.0 : (ff > 1.0 ? 1.0 : ff);
+        fl = fl < 0.0 ? 0.0 : (fl > 1.0 ? 1.0 : fl);
+        fr = fr < 0.0 ? 0.0 : (fr > 1.0 ? 1.0 : fr);
+        act *= ff;
+        hl = M.rate_diffusion * (double)open_l * fl;
+        hr = M.rate_diffusion * (double)open_r * fr;
+        diff = hl + hr;
+    }
+    if (held) { diff = 0.0; act = 0.0; }
+    Channels c;
+    c.bind = (!bound && !plus && anchored_site && occ_self < K) ? M.k_on : 0.0;
+    c.unbind = bound ? M.k_off : 0.0;
+    c.diff = diff; c.act = act; c.flip = flip; c.leave = leave; c.left = hl; c.right = hr;
+    c.total = ((((diff + act) + flip) + c.bind) + c.unbind) + leave;
+    return c;
+}
+
+// The read-only arrays are separate `const __restrict__` kernel parameters (not struct members) so that
+// the compiler can prove the wave-uniform source reads are never clobbered and emit scalar loads.
+template <int BC, bool TAB_LDS>
+__global__ __launch_bounds__(TILE *WAVES) void pair_propose(const PairArgs a, const uint32_t *__restrict__ src_all,
+                                                           const int2 *__restrict__ bounds_all,
+                                                           const double *__restrict__ table_g) {
+    extern __shared__ double lds[];
+    const Model &M = a.m;
+    const int e = blockIdx.y;
+    const int ttile = a.tile_lo + blockIdx.x;
+    const int lane = threadIdx.x & (TILE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // the commit that follows this launch needs empty per-site proposer counters
+    {
+        const size_t total = (size_t)a.E * (size_t)M.L;
+        const size_t nthreads = (size_t)gridDim.x * gridDim.y * blockDim.x;
+        const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        for (size_t i = gtid; i < total; i += nthreads) a.pcnt[i] = 0u;
+    }
+
+    const double *tab = table_g;
+    double *part = lds;                                       // [WAVES][TILE][4] partial sums
+    if (TAB_LDS) {
+        for (int i = threadIdx.x; i <= a.tlen; i += TILE * WAVES) lds[i] = table_g[i];
+        tab = lds;
+        part = lds + (a.tlen + 1);
+    }
+    __syncthreads();
+
+    const uint32_t *__restrict__ src_e = src_all + (size_t)e * a.Npad;
+    const int2 *__restrict__ bounds_e = bounds_all + (size_t)e * a.ntiles;
+    const uint32_t me = src_e[(size_t)ttile * TILE + lane];
+    const uint32_t pi8 = (me & POS_MASK) << 3;
+    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)M.L << 3;
+    const int R = a.tlen > 1 ? a.tlen - 1 : 1;               // reach in sites (>= 1 for the occupancy test)
+
+    double accW = 0.0, accS = 0.0;
+    int c0 = 0, cl = 0, cr = 0;
+    unsigned done = 0;
+    const int2 tb = bounds_e[ttile];
+    if (tb.x <= tb.y) {
+        for (int jt = wave; jt < a.ntiles; jt += WAVES) {
+            const int2 sb = bounds_e[jt];
+            if (sb.x > sb.y) continue;                       // tile holds no live particle
+            bool direct, mirror;
+            tile_tests<BC>(tb.x, tb.y, sb.x, sb.y, R, M.L, direct, mirror);
+            if (!(direct || mirror)) continue;
+            const uint32_t *__restrict__ tile = src_e + (size_t)jt * TILE;
+            if (BC == 0 && mirror) tile_loop<BC, true>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
+            else tile_loop<BC, false>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
+            ++done;
+        }
+    }
+    if (lane == 0 && done && a.tiles_done) atomicAdd(a.tiles_done, (unsigned long long)done);
+
+    // combine the four waves' partial sums (exact on the weight grid, so the order is irrelevant)
+    double *mine = part + ((size_t)wave * TILE + lane) * 4;
+    mine[0] = accW; mine[1] = accS;
+    reinterpret_cast<int *>(mine + 2)[0] = c0; reinterpret_cast<int *>(mine + 2)[1] = cl;
+    reinterpret_cast<int *>(mine + 3)[0] = cr;
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < WAVES; ++w) {
+        const double *o = part + ((size_t)w * TILE + lane) * 4;
+        accW += o[0]; accS += o[1];
+        c0 += reinterpret_cast<const int *>(o + 2)[0]; cl += reinterpret_cast<const int *>(o + 2)[1];
+        cr += reinterpret_cast<const int *>(o + 3)[0];
+    }
+
+    // ---------------- epilogue: one lane = one target particle
+    const size_t slot = (size_t)ttile * TILE + lane;
+    const bool live = !(me & DEAD_BIT);
+    const int p = (int)(me & POS_MASK);
+    const int spin = (me & SPIN_BIT) ? 1 : -1;
+    const bool bound = (me & BOUND_BIT) != 0;
+    if (M.field_mode == 0) {                                  // global mean field (ref :219-221)
+        accS = (double)a.gsum[2 * e]; accW = (double)a.gsum[2 * e + 1];
+    }
+    if (!live) { accS = 0.0; accW = 0.0; c0 = cl = cr = 0; }
+    const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == M.L - 1;
+    if (a.S_out) {
+        a.S_out[(size_t)e * a.Npad + slot] = accS;
+        a.W_out[(size_t)e * a.Npad + slot] = accW;
+        int *o = a.occ4_out + ((size_t)e * a.Npad + slot) * 4;
+        const int o_l = wall_l ? c0 : cl, o_r = wall_r ? c0 : cr;
+        o[0] = c0; o[1] = live ? (spin > 0 ? o_r : c0) : 0; o[2] = live ? o_l : 0; o[3] = live ? o_r : 0;
+    }
+    if (!a.write_prop) return;
+    uint8_t code = EV_NONE;
+    if (live) {
+        double mloc = 0.0;
+        if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+        const bool anch = a.anchor ? a.anchor[p] != 0 : false;
+        const Channels c = channels(M, anch, p, spin, bound, mloc, a.beta[e], c0, cl, cr);
+        uint32_t x[4];
+        philox4x32_10(a.step_lo, a.step_hi, a.orig[(size_t)e * a.Npad + slot], (uint32_t)(M.ens_base + e),
+                      M.seed_lo, M.seed_hi, x);
+        const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
+        const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
+        const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
+        if (u0 < p_fire) {
+            const double v = u1 * c.total;
+            const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
+                         e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
+            int ev = EV_NONE, occ_t = 0;
+            if (v < e_diff) {
+                if (c.left + c.right > 0.0) {
+                    if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
+                    else { ev = EV_RIGHT; occ_t = cr; }
+                }
+            } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
+            else if (v < e_bind) ev = EV_BIND;
+            else if (v < e_unbind) ev = EV_UNBIND;
+            else if (v < e_exit) ev = EV_EXIT;
+            else ev = EV_FLIP;
+            int cap = M.K - occ_t;                           // free capacity of the hop target at step start
+            cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
+            code = (uint8_t)(ev | ((cap - 1) << 3));
+        }
+    }
+    const int r = (int)(slot / a.SH);
+    a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct CommitArgs {
+    Model m;
+    uint32_t *src; const uint32_t *orig; const uint8_t *prop;
+    uint32_t *pcnt, *plist; int2 *bounds; long long *gsum;
+    double *exit_log; unsigned *n_exit; int exit_cap;
+    int Npad, SH, E, ntiles;
+    double step_as_double;
+};
+
+__device__ inline int hop_target(const Model &M, int p, int ev) {
+    int s = (ev == EV_LEFT) ? p - 1 : p + 1;
+    if (M.periodic) s = s < 0 ? s + M.L : (s >= M.L ? s - M.L : s);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void claim(const CommitArgs a) {
+    const int e = blockIdx.y;
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot == 0) { a.gsum[2 * e] = 0; a.gsum[2 * e + 1] = 0; }      // apply() re-accumulates them
+    if (slot >= (size_t)a.Npad) return;
+    const int r = (int)(slot / a.SH);
+    const uint8_t code = a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)];
+    const int ev = code & 7;
+    if (ev != EV_LEFT && ev != EV_RIGHT && ev != EV_FWD) return;
+    const uint32_t me = a.src[(size_t)e * a.Npad + slot];
+    const int s = hop_target(a.m, (int)(me & POS_MASK), ev);
+    const size_t site = (size_t)e * a.m.L + s;
+    const uint32_t k = atomicAdd(&a.pcnt[site], 1u);
+    if (k < 2u * a.m.K) a.plist[site * 2 * a.m.K + k] = a.orig[(size_t)e * a.Npad + slot];
+}
+
+__global__ __launch_bounds__(256) void apply(const CommitArgs a) {
+    const int e = blockIdx.y;
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // Npad is a multiple of 256
+    const int r = (int)(slot / a.SH);
+    const uint8_t code = a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)];
+    const int ev = code & 7;
+    uint32_t me = a.src[(size_t)e * a.Npad + slot];
+    const uint32_t my_orig = a.orig[(size_t)e * a.Npad + slot];
+    int p = (int)(me & POS_MASK);
+    if (!(me & DEAD_BIT)) {
+        if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
+            const int s = hop_target(a.m, p, ev);
+            const size_t site = (size_t)e * a.m.L + s;
+            const uint32_t n = min(a.pcnt[site], 2u * a.m.K);
+            int rank = 0;                                     // proposers to s with a smaller particle index
+            for (uint32_t k = 0; k < n; ++k) rank += a.plist[site * 2 * a.m.K + k] < my_orig;
+            if (rank < (code >> 3) + 1) { p = s; me = (me & ~POS_MASK) | (uint32_t)s; }
+        } else if (ev == EV_BIND) me |= BOUND_BIT;
+        else if (ev == EV_UNBIND) me &= ~BOUND_BIT;
+        else if (ev == EV_FLIP) me ^= SPIN_BIT;
+        else if (ev == EV_EXIT) {
+            me |= DEAD_BIT;
+            const unsigned k = atomicAdd(&a.n_exit[e], 1u);
+            if ((int)k < a.exit_cap) {
+                double *row = a.exit_log + ((size_t)e * a.exit_cap + k) * 3;
+                row[0] = a.step_as_double; row[1] = (double)p; row[2] = (double)my_orig;
+            }
+        }
+        if (ev != EV_NONE) a.src[(size_t)e * a.Npad + slot] = me;
+    }
+    // per-tile (= per-wave) bounds of the live sites, and the global spin sums
+    const bool live = !(me & DEAD_BIT);
+    int lo = live ? p : 0x7fffffff, hi = live ? p : -1;
+    int ssum = live ? ((me & SPIN_BIT) ? 1 : -1) : 0, cnt = live ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off));
+        ssum += __shfl_xor(ssum, off); cnt += __shfl_xor(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        a.bounds[(size_t)e * a.ntiles + slot / TILE] = make_int2(lo, hi);
+        if (a.m.field_mode == 0 && cnt) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e]), (unsigned long long)(long long)ssum);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e + 1]), (unsigned long long)cnt);
+        }
+    }
+}
+
+// m-field on lattice sites: the same tile loop with the targets being sites instead of particles.
+struct FieldArgs {
+    Model m; const long long *gsum;
+    double *m_out; int tlen, ntiles, e;
+};
+
+template <int BC, bool TAB_LDS>
+__global__ __launch_bounds__(TILE *WAVES) void field_sites(const FieldArgs a, const uint32_t *__restrict__ src,
+                                                          const int2 *__restrict__ bounds,
+                                                          const double *__restrict__ table_g) {
+    extern __shared__ double lds[];
+    const Model &M = a.m;
+    const int lane = threadIdx.x & (TILE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double *tab = table_g;
+    double *part = lds;
+    if (TAB_LDS) {
+        for (int i = threadIdx.x; i <= a.tlen; i += TILE * WAVES) lds[i] = table_g[i];
+        tab = lds; part = lds + (a.tlen + 1);
+    }
+    __syncthreads();
+    const int x = blockIdx.x * TILE + lane;
+    const int tlo = blockIdx.x * TILE, thi = min(tlo + TILE - 1, M.L - 1);
+    const uint32_t pi8 = (uint32_t)min(x, M.L - 1) << 3;
+    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)M.L << 3;
+    const int R = a.tlen > 1 ? a.tlen - 1 : 1;
+    double accW = 0.0, accS = 0.0;
+    int c0 = 0, cl = 0, cr = 0;
+    for (int jt = wave; jt < a.ntiles; jt += WAVES) {
+        const int2 sb = bounds[jt];
+        if (sb.x > sb.y) continue;
+        bool direct, mirror;
+        tile_tests<BC>(tlo, thi, sb.x, sb.y, R, M.L, direct, mirror);
+        if (!(direct || mirror)) continue;
+        const uint32_t *__restrict__ tile = src + (size_t)jt * TILE;
+        if (BC == 0 && mirror) tile_loop<BC, true>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
+        else tile_loop<BC, false>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
+    }
+    double *mine = part + ((size_t)wave * TILE + lane) * 2;
+    mine[0] = accW; mine[1] = accS;
+    __syncthreads();
+    if (wave != 0 || x >= M.L) return;
+    for (int w = 1; w < WAVES; ++w) { accW += part[((size_t)w * TILE + lane) * 2]; accS += part[((size_t)w * TILE + lane) * 2 + 1]; }
+    if (M.field_mode == 0) { accS = (double)a.gsum[2 * a.e]; accW = (double)a.gsum[2 * a.e + 1]; }
+    double mloc = 0.0;
+    if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+    a.m_out[x] = mloc;
+}
+
+// ---------------------------------------------------------------------------------------------
+std::string g_create_error;
+
+}  // namespace
+
+struct aps_handle {
+    aps_params p{};
+    Model model{};
+    std::vector<double> beta;
+    std::vector<double> table;     // tlen + 1 entries, last one 0
+    int tlen = 0, q = 0;
+    bool table_in_lds = true;
+    size_t lds_bytes = 0, lds_bytes_field = 0;
+    int E = 1, world = 1, rank = 0;
+    int64_t N = 0, Npad = 0, SH = 0, ntiles = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t *d_src = nullptr, *d_orig = nullptr, *d_pcnt = nullptr, *d_plist = nullptr;
+    uint8_t *d_prop = nullptr, *d_prop_own = nullptr, *d_anchor = nullptr;
+    int2 *d_bounds = nullptr;
+    double *d_table = nullptr, *d_beta = nullptr, *d_exit = nullptr, *d_S = nullptr, *d_W = nullptr, *d_mfield = nullptr;
+    int *d_occ4 = nullptr;
+    long long *d_gsum = nullptr;
+    unsigned *d_nexit = nullptr;
+    unsigned long long *d_tiles = nullptr;
+    uint32_t *d_tmp_src = nullptr; int2 *d_tmp_bounds = nullptr; size_t tmp_cap = 0;
+    int exit_cap = 0;
+    int64_t step = 0;
+    std::vector<int64_t> n_set;    // particles uploaded per ensemble
+    std::vector<hipEvent_t> events;
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return APS_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+int fail(aps_handle *h, int code, const std::string &msg) { h->err = msg; return code; }
+
+// Weight table (DESIGN.md "Weight table"): unnormalised taps of gaussian_filter1d(truncate=4) with the
+// reflected images folded in, rounded to the grid 2^-q that keeps every possible partial sum exact.
+void build_table(aps_handle *h) {
+    const aps_params &p = h->p;
+    h->table.clear();
+    h->q = 0;
+    if (!(p.sigma_grid > 0.0)) { h->tlen = 0; h->table.push_back(0.0); return; }
+    const double s2 = p.sigma_grid * p.sigma_grid;
+    const int64_t L = p.L;
+    const int64_t lw = p.periodic ? L / 2 : (int64_t)(4.0 * p.sigma_grid + 0.5);
+    const int64_t tmax = p.periodic ? L / 2 : std::min(lw, L);
+    std::vector<double> w((size_t)tmax + 1);
+    double wmax = 0.0;
+    for (int64_t t = 0; t <= tmax; ++t) {
+        double acc = 0.0;
+        if (p.periodic) {
+            const double a = (double)t;
+            acc = aps_exp(-(0.5 * a * a) / s2);
+        } else {
+            for (int64_t k = 0;; ++k) {
+                const int64_t d1 = t + 2 * L * k, d2 = 2 * L * k - t;
+                bool any = false;
+                if (d1 <= lw) { const double a = (double)d1; acc += aps_exp(-(0.5 * a * a) / s2); any = true; }
+                if (k > 0 && d2 <= lw) { const double a = (double)d2; acc += aps_exp(-(0.5 * a * a) / s2); any = true; }
+                if (!any) break;
+            }
+        }
+        w[(size_t)t] = acc;
+        wmax = std::max(wmax, acc);
+    }
+    const double nterm = p.periodic ? (double)p.K * (2.0 * (double)tmax + 1.0)
+                                    : (lw < L ? (double)p.K * (2.0 * (double)lw + 1.0) : 2.0 * (double)p.K * (double)L);
+    const double bound = std::ceil(nterm * wmax);
+    int bits = 0;
+    while (std::ldexp(1.0, bits) <= bound) ++bits;
+    int q = std::min(45, 51 - bits);
+    const double up = std::ldexp(1.0, q), down = std::ldexp(1.0, -q);
+    int n = 0;
+    for (int64_t t = 0; t <= tmax; ++t) {
+        w[(size_t)t] = std::rint(w[(size_t)t] * up) * down;
+        if (w[(size_t)t] != 0.0) n = (int)t + 1;
+    }
+    w.resize((size_t)n);
+    w.push_back(0.0);
+    h->table = std::move(w);
+    h->tlen = n;
+    h->q = q;
+}
+
+template <typename T>
+int dev_alloc(aps_handle *h, T **ptr, size_t count) {
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(h, hipMemsetAsync(*ptr, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
+    return APS_OK;
+}
+
+// host-side packing of one ensemble into slot order; fills bounds and the global sums
+void pack_ensemble(const aps_handle *h, const int32_t *pos, const int8_t *sigma, const uint8_t *bound,
+                   const uint8_t *alive, int64_t n, std::vector<uint32_t> &src, std::vector<uint32_t> &orig,
+                   std::vector<int2> &bounds, long long gsum[2]) {
+    const int64_t Npad = h->Npad;
+    std::vector<uint32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (h->p.sort_by_site)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const bool da = alive && !alive[a], db = alive && !alive[b];
+            if (da != db) return db;                       // live particles first
+            return pos[a] < pos[b];
+        });
+    src.assign((size_t)Npad, DEAD_BIT);
+    orig.assign((size_t)Npad, 0xFFFFFFFFu);
+    gsum[0] = gsum[1] = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        const uint32_t i = order[(size_t)s];
+        uint32_t w = (uint32_t)pos[i] & POS_MASK;
+        if (sigma[i] > 0) w |= SPIN_BIT;
+        if (bound && bound[i]) w |= BOUND_BIT;
+        const bool dead = alive && !alive[i];
+        if (dead) w |= DEAD_BIT;
+        else { gsum[0] += sigma[i] > 0 ? 1 : -1; gsum[1] += 1; }
+        src[(size_t)s] = w;
+        orig[(size_t)s] = i;
+    }
+    bounds.assign((size_t)h->ntiles, make_int2(0x7fffffff, -1));
+    for (int64_t s = 0; s < Npad; ++s) {
+        if (src[(size_t)s] & DEAD_BIT) continue;
+        int2 &b = bounds[(size_t)(s / TILE)];
+        const int p = (int)(src[(size_t)s] & POS_MASK);
+        b.x = std::min(b.x, p); b.y = std::max(b.y, p);
+    }
+}
+
+PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
+    PairArgs a{};
+    a.m = h->model;
+    a.orig = h->d_orig; a.gsum = h->d_gsum;
+    a.beta = h->d_beta; a.anchor = h->d_anchor; a.prop = h->d_prop; a.pcnt = h->d_pcnt;
+    a.S_out = hook ? h->d_S : nullptr; a.W_out = hook ? h->d_W : nullptr; a.occ4_out = hook ? h->d_occ4 : nullptr;
+    a.tiles_done = h->d_tiles;
+    a.tlen = h->tlen; a.Npad = (int)h->Npad; a.SH = (int)h->SH; a.E = h->E; a.ntiles = (int)h->ntiles;
+    a.tile_lo = (int)(h->rank * h->SH / TILE); a.tile_cnt = (int)(h->SH / TILE);
+    a.step_lo = (uint32_t)h->step; a.step_hi = (uint32_t)((uint64_t)h->step >> 32);
+    a.write_prop = write_prop ? 1 : 0;
+    return a;
+}
+
+int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) {
+    PairArgs b = a;
+    b.tile_lo = first_tile; b.tile_cnt = tile_cnt;
+    const dim3 grid((unsigned)tile_cnt, (unsigned)h->E), block(TILE * WAVES);
+    const size_t part = (size_t)WAVES * TILE * 4 * sizeof(double);
+    const size_t lds = h->table_in_lds ? (size_t)(h->tlen + 1) * sizeof(double) + part : part;
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_propose<BC, TL>), grid, block, lds, h->stream, b, h->d_src, h->d_bounds, h->d_table)
+    if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
+    else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
+#undef APS_LAUNCH
+    HIP_TRY(h, hipGetLastError());
+    return APS_OK;
+}
+
+CommitArgs commit_args(aps_handle *h) {
+    CommitArgs c{};
+    c.m = h->model; c.src = h->d_src; c.orig = h->d_orig; c.prop = h->d_prop; c.pcnt = h->d_pcnt;
+    c.plist = h->d_plist; c.bounds = h->d_bounds; c.gsum = h->d_gsum; c.exit_log = h->d_exit;
+    c.n_exit = h->d_nexit; c.exit_cap = h->exit_cap; c.Npad = (int)h->Npad; c.SH = (int)h->SH; c.E = h->E;
+    c.ntiles = (int)h->ntiles; c.step_as_double = (double)h->step;
+    return c;
+}
+
+int set_lds_limit(aps_handle *h) {
+    const size_t part = (size_t)WAVES * TILE * 4 * sizeof(double);
+    const size_t need = (size_t)(h->tlen + 1) * sizeof(double) + part;
+    h->table_in_lds = need <= 150 * 1024;
+    if (h->table_in_lds && need > 48 * 1024) {
+        const int n = (int)need;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_propose<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_propose<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+    }
+    return APS_OK;
+}
+
+int launch_field(aps_handle *h, int e, const uint32_t *src, const int2 *bounds, int ntiles, double *m_out) {
+    FieldArgs f{};
+    f.m = h->model; f.gsum = h->d_gsum; f.m_out = m_out;
+    f.tlen = h->tlen; f.ntiles = ntiles; f.e = e;
+    const dim3 grid((unsigned)((h->p.L + TILE - 1) / TILE)), block(TILE * WAVES);
+    const size_t part = (size_t)WAVES * TILE * 2 * sizeof(double);
+    const size_t lds = h->table_in_lds ? (size_t)(h->tlen + 1) * sizeof(double) + part : part;
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, src, bounds, h->d_table)
+    if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
+    else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
+#undef APS_LAUNCH
+    HIP_TRY(h, hipGetLastError());
+    return APS_OK;
+}
+
+int do_propose(aps_handle *h) {
+    const PairArgs a = pair_args(h, false, true);
+    return launch_pair(h, a, a.tile_lo, a.tile_cnt);
+}
+
+int do_commit(aps_handle *h) {
+    const CommitArgs c = commit_args(h);
+    const dim3 grid((unsigned)(h->Npad / 256), (unsigned)h->E), block(256);
+    hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);
+    hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
+    HIP_TRY(h, hipGetLastError());
+    h->step += 1;
+    return APS_OK;
+}
+
+bool all_set(const aps_handle *h) {
+    for (int64_t n : h->n_set) if (n < 0) return false;
+    return true;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" {
+
+int aps_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *aps_last_error(const aps_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int aps_create(const aps_params *p, aps_handle **out) {
+    if (!p || !out) { g_create_error = "aps_create: null argument"; return APS_ERR_ARG; }
+    *out = nullptr;
+    auto bad = [&](const char *m) { g_create_error = std::string("aps_create: ") + m; return APS_ERR_ARG; };
+    if (p->L < 2 || p->L > (1 << 25)) return bad("L must be in [2, 2^25]");
+    if (p->K < 1 || p->K > 32) return bad("site capacity K must be in [1, 32]");
+    if (p->n_ensembles < 1) return bad("n_ensembles must be >= 1");
+    if (p->n_particles < 0 || p->n_particles > (int64_t)p->K * p->L) return bad("n_particles must be in [0, K*L]");
+    if (!(p->dt > 0.0)) return bad("dt must be > 0");
+    if (!p->beta) return bad("beta pointer is null");
+    if (p->world < 1 || p->rank < 0 || p->rank >= p->world) return bad("bad rank/world");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "aps_create: no HIP device"; return APS_ERR_NODEVICE; }
+    if (p->device < 0 || p->device >= ndev) return bad("device ordinal out of range");
+
+    aps_handle *h = new aps_handle();
+    h->p = *p;
+    h->beta.assign(p->beta, p->beta + p->n_ensembles);
+    h->p.beta = nullptr;
+    h->E = p->n_ensembles; h->world = p->world; h->rank = p->rank; h->N = p->n_particles;
+    // shard length: whole 256-slot groups so that apply()'s blocks and the 64-slot tiles never straddle ranks
+    const int64_t per_rank = (h->N + h->world - 1) / h->world;
+    h->SH = std::max<int64_t>(256, (per_rank + 255) / 256 * 256);
+    h->Npad = h->SH * h->world;
+    h->ntiles = h->Npad / TILE;
+    h->n_set.assign((size_t)h->E, -1);
+    Model &M = h->model;
+    M.L = p->L; M.K = p->K; M.periodic = p->periodic ? 1 : 0; M.field_mode = p->sigma_grid > 0.0 ? 1 : 0;
+    M.minus_anchor = p->minus_anchor ? 1 : 0; M.immobilize = p->immobilize ? 1 : 0;
+    M.suppress_flip = p->suppress_flip ? 1 : 0; M.crowding = p->crowding ? 1 : 0;
+    M.rate_diffusion = p->rate_diffusion; M.rate_active = p->rate_active; M.k_on = p->k_on; M.k_off = p->k_off;
+    M.k_exit = p->k_exit; M.dt = p->dt; M.seed_lo = (uint32_t)p->seed; M.seed_hi = (uint32_t)(p->seed >> 32);
+    M.ens_base = p->ensemble_base;
+    build_table(h);
+
+    auto die = [&](int code) { g_create_error = h->err; aps_destroy(h); return code; };
+    if (hipSetDevice(p->device) != hipSuccess) { h->err = "hipSetDevice failed"; return die(APS_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return die(APS_ERR_HIP); }
+    h->own_stream = true;
+    int rc = set_lds_limit(h);
+    if (rc) return die(rc);
+    const size_t EN = (size_t)h->E * (size_t)h->Npad, EL = (size_t)h->E * (size_t)p->L;
+    h->exit_cap = (int)std::max<int64_t>(h->N, 1);
+    if ((rc = dev_alloc(h, &h->d_src, EN)) || (rc = dev_alloc(h, &h->d_orig, EN)) || (rc = dev_alloc(h, &h->d_prop_own, EN)) ||
+        (rc = dev_alloc(h, &h->d_bounds, (size_t)h->E * h->ntiles)) || (rc = dev_alloc(h, &h->d_pcnt, EL)) ||
+        (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size())) ||
+        (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)2 * h->E)) ||
+        (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
+        (rc = dev_alloc(h, &h->d_tiles, 1)) || (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))
+        return die(rc);
+    h->d_prop = h->d_prop_own;
+    if (p->anchor_mask) {
+        if ((rc = dev_alloc(h, &h->d_anchor, (size_t)p->L))) return die(rc);
+        if (hipMemcpyAsync(h->d_anchor, p->anchor_mask, (size_t)p->L, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "anchor upload failed"; return die(APS_ERR_HIP); }
+    }
+    h->p.anchor_mask = nullptr;
+    if (hipMemcpyAsync(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(h->d_beta, h->beta.data(), h->beta.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "table upload failed"; return die(APS_ERR_HIP); }
+    *out = h;
+    return APS_OK;
+}
+
+void aps_destroy(aps_handle *h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
+    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_bounds, h->d_table, h->d_beta,
+                    h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum, h->d_nexit, h->d_tiles, h->d_tmp_src,
+                    h->d_tmp_bounds};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int aps_set_stream(aps_handle *h, void *hip_stream) {
+    if (!h) return APS_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) { HIP_TRY(h, hipStreamDestroy(h->stream)); h->own_stream = false; }
+    if (hip_stream) h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    else { HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    return APS_OK;
+}
+
+int aps_set_state(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *sigma, const uint8_t *bound,
+                  const uint8_t *alive, int64_t n) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !pos || !sigma || n < 0 || n > h->N) return fail(h, APS_ERR_ARG, "aps_set_state: bad ensemble, pointer or n");
+    std::vector<int> occ((size_t)h->p.L, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (pos[i] < 0 || pos[i] >= h->p.L) return fail(h, APS_ERR_ARG, "aps_set_state: position outside [0, L)");
+        if (sigma[i] != 1 && sigma[i] != -1) return fail(h, APS_ERR_ARG, "aps_set_state: sigma must be +1 or -1");
+        if (!(alive && !alive[i]) && ++occ[(size_t)pos[i]] > h->p.K) return fail(h, APS_ERR_ARG, "aps_set_state: site capacity exceeded");
+    }
+    std::vector<uint32_t> src, orig; std::vector<int2> bounds; long long gsum[2];
+    pack_ensemble(h, pos, sigma, bound, alive, n, src, orig, bounds, gsum);
+    HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_bounds + (size_t)e * h->ntiles, bounds.data(), bounds.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gsum, sizeof(gsum), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_nexit + e, 0, sizeof(unsigned), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_set[(size_t)e] = n;
+    return APS_OK;
+}
+
+int aps_get_state(aps_handle *h, int32_t e, int32_t *pos, int8_t *sigma, uint8_t *bound, uint8_t *alive, int64_t n) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_get_state: bad ensemble");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_get_state: no state uploaded for this ensemble");
+    if (n != h->n_set[(size_t)e]) return fail(h, APS_ERR_ARG, "aps_get_state: n differs from the uploaded particle count");
+    std::vector<uint32_t> src((size_t)h->Npad), orig((size_t)h->Npad);
+    HIP_TRY(h, hipMemcpyAsync(src.data(), h->d_src + (size_t)e * h->Npad, src.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(orig.data(), h->d_orig + (size_t)e * h->Npad, orig.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int64_t s = 0; s < h->Npad; ++s) {
+        const uint32_t i = orig[(size_t)s];
+        if (i == 0xFFFFFFFFu) continue;
+        if (i >= (uint64_t)n) return fail(h, APS_ERR_STATE, "aps_get_state: corrupt slot table");
+        const uint32_t w = src[(size_t)s];
+        if (pos) pos[i] = (int32_t)(w & POS_MASK);
+        if (sigma) sigma[i] = (w & SPIN_BIT) ? 1 : -1;
+        if (bound) bound[i] = (w & BOUND_BIT) ? 1 : 0;
+        if (alive) alive[i] = (w & DEAD_BIT) ? 0 : 1;
+    }
+    return APS_OK;
+}
+
+int aps_pair_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t *occ4, int64_t n) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !S || !W || !occ4) return fail(h, APS_ERR_ARG, "aps_pair_accumulate: bad argument");
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_pair_accumulate: upload a state for every ensemble first");
+    if (n != h->n_set[(size_t)e]) return fail(h, APS_ERR_ARG, "aps_pair_accumulate: n differs from the uploaded particle count");
+    const size_t EN = (size_t)h->E * (size_t)h->Npad;
+    int rc;
+    if (!h->d_S && ((rc = dev_alloc(h, &h->d_S, EN)) || (rc = dev_alloc(h, &h->d_W, EN)) || (rc = dev_alloc(h, &h->d_occ4, EN * 4)))) return rc;
+    const PairArgs a = pair_args(h, true, false);
+    if ((rc = launch_pair(h, a, 0, (int)h->ntiles))) return rc;            // the hook covers every tile, not only this rank's
+    std::vector<double> s((size_t)h->Npad), w((size_t)h->Npad); std::vector<int> o((size_t)h->Npad * 4); std::vector<uint32_t> orig((size_t)h->Npad);
+    HIP_TRY(h, hipMemcpyAsync(s.data(), h->d_S + (size_t)e * h->Npad, s.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(w.data(), h->d_W + (size_t)e * h->Npad, w.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(o.data(), h->d_occ4 + (size_t)e * h->Npad * 4, o.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(orig.data(), h->d_orig + (size_t)e * h->Npad, orig.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int64_t sl = 0; sl < h->Npad; ++sl) {
+        const uint32_t i = orig[(size_t)sl];
+        if (i == 0xFFFFFFFFu) continue;
+        S[i] = s[(size_t)sl]; W[i] = w[(size_t)sl];
+        for (int k = 0; k < 4; ++k) occ4[4 * (size_t)i + k] = o[4 * (size_t)sl + k];
+    }
+    return APS_OK;
+}
+
+int aps_propose(aps_handle *h) {
+    if (!h) return APS_ERR_ARG;
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_propose: upload a state for every ensemble first");
+    return do_propose(h);
+}
+
+int aps_commit(aps_handle *h) {
+    if (!h) return APS_ERR_ARG;
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_commit: upload a state for every ensemble first");
+    return do_commit(h);
+}
+
+int aps_step(aps_handle *h, int64_t nsteps) {
+    if (!h) return APS_ERR_ARG;
+    if (nsteps < 0) return fail(h, APS_ERR_ARG, "aps_step: nsteps < 0");
+    if (h->world != 1) return fail(h, APS_ERR_STATE, "aps_step: sharded handle; use aps_propose / exchange / aps_commit");
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step: upload a state for every ensemble first");
+    for (int64_t s = 0; s < nsteps; ++s) {
+        int rc;
+        if ((rc = do_propose(h)) || (rc = do_commit(h))) return rc;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_t *launches, double *pairs) {
+    if (!h) return APS_ERR_ARG;
+    if (nsteps < 0 || !pair_kernel_ms) return fail(h, APS_ERR_ARG, "aps_step_timed: bad argument");
+    if (h->world != 1) return fail(h, APS_ERR_STATE, "aps_step_timed: sharded handle");
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step_timed: upload a state for every ensemble first");
+    while ((int64_t)h->events.size() < 2 * nsteps) {
+        hipEvent_t ev;
+        HIP_TRY(h, hipEventCreate(&ev));
+        h->events.push_back(ev);
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_tiles, 0, sizeof(unsigned long long), h->stream));
+    for (int64_t s = 0; s < nsteps; ++s) {
+        int rc;
+        HIP_TRY(h, hipEventRecord(h->events[(size_t)(2 * s)], h->stream));
+        if ((rc = do_propose(h))) return rc;
+        HIP_TRY(h, hipEventRecord(h->events[(size_t)(2 * s + 1)], h->stream));
+        if ((rc = do_commit(h))) return rc;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    for (int64_t s = 0; s < nsteps; ++s) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->events[(size_t)(2 * s)], h->events[(size_t)(2 * s + 1)]));
+        total += ms;
+    }
+    *pair_kernel_ms = total;
+    if (launches) *launches = nsteps;
+    if (pairs) {
+        unsigned long long t = 0;
+        HIP_TRY(h, hipMemcpy(&t, h->d_tiles, sizeof(t), hipMemcpyDeviceToHost));
+        *pairs = (double)t * TILE * TILE;
+    }
+    return APS_OK;
+}
+
+int aps_exchange_buffer(aps_handle *h, void **dev_ptr, int64_t *total_bytes, int64_t *my_offset, int64_t *my_bytes) {
+    if (!h) return APS_ERR_ARG;
+    const int64_t block = (int64_t)h->E * h->SH;
+    if (dev_ptr) *dev_ptr = h->d_prop;
+    if (total_bytes) *total_bytes = block * h->world;
+    if (my_offset) *my_offset = block * h->rank;
+    if (my_bytes) *my_bytes = block;
+    return APS_OK;
+}
+
+int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes) {
+    if (!h) return APS_ERR_ARG;
+    if (!dev_ptr) { h->d_prop = h->d_prop_own; return APS_OK; }
+    if (nbytes < (int64_t)h->E * h->SH * h->world) return fail(h, APS_ERR_ARG, "aps_bind_exchange_buffer: buffer too small");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->d_prop = static_cast<uint8_t *>(dev_ptr);
+    return APS_OK;
+}
+
+int aps_time(aps_handle *h, double *t, int64_t *step_index) {
+    if (!h) return APS_ERR_ARG;
+    if (t) *t = (double)h->step * h->p.dt;
+    if (step_index) *step_index = h->step;
+    return APS_OK;
+}
+
+int aps_get_table(aps_handle *h, double *out, int32_t cap, int32_t *tlen, int32_t *q) {
+    if (!h) return APS_ERR_ARG;
+    if (tlen) *tlen = h->tlen;
+    if (q) *q = h->q;
+    if (out) {
+        if (cap < h->tlen) return fail(h, APS_ERR_ARG, "aps_get_table: buffer too small");
+        std::memcpy(out, h->table.data(), (size_t)h->tlen * sizeof(double));
+    }
+    return APS_OK;
+}
+
+int aps_get_exits(aps_handle *h, int32_t e, double *rows3, int64_t cap_rows, int64_t *n_rows) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !n_rows) return fail(h, APS_ERR_ARG, "aps_get_exits: bad argument");
+    unsigned n = 0;
+    HIP_TRY(h, hipMemcpyAsync(&n, h->d_nexit + e, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    n = std::min<unsigned>(n, (unsigned)h->exit_cap);
+    *n_rows = n;
+    if (!rows3 || !n) return APS_OK;
+    if (cap_rows < (int64_t)n) return fail(h, APS_ERR_ARG, "aps_get_exits: buffer too small");
+    std::vector<double> raw((size_t)n * 3);
+    HIP_TRY(h, hipMemcpy(raw.data(), h->d_exit + (size_t)e * h->exit_cap * 3, raw.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned> idx(n);
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) {
+        if (raw[3 * a] != raw[3 * b]) return raw[3 * a] < raw[3 * b];
+        return raw[3 * a + 2] < raw[3 * b + 2];
+    });
+    for (unsigned k = 0; k < n; ++k) {
+        rows3[3 * k] = raw[3 * idx[k]] * h->p.dt;           // logged step index -> time of the step's start
+        rows3[3 * k + 1] = raw[3 * idx[k] + 1];
+        rows3[3 * k + 2] = raw[3 * idx[k] + 2];
+    }
+    return APS_OK;
+}
+
+int aps_resort(aps_handle *h) {
+    if (!h) return APS_ERR_ARG;
+    if (!h->p.sort_by_site) return APS_OK;
+    for (int e = 0; e < h->E; ++e) {
+        const int64_t n = h->n_set[(size_t)e];
+        if (n < 0) continue;
+        std::vector<int32_t> pos((size_t)n); std::vector<int8_t> sg((size_t)n); std::vector<uint8_t> bd((size_t)n), al((size_t)n);
+        int rc = aps_get_state(h, e, pos.data(), sg.data(), bd.data(), al.data(), n);
+        if (rc) return rc;
+        std::vector<uint32_t> src, orig; std::vector<int2> bounds; long long gsum[2];
+        pack_ensemble(h, pos.data(), sg.data(), bd.data(), al.data(), n, src, orig, bounds, gsum);
+        HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_bounds + (size_t)e * h->ntiles, bounds.data(), bounds.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return APS_OK;
+}
+
+int aps_observe(aps_handle *h, int32_t e, int64_t *counts_p, int64_t *counts_m, double *m_field) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_observe: bad ensemble");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_observe: no state uploaded for this ensemble");
+    const int L = h->p.L;
+    if (counts_p || counts_m) {
+        std::vector<uint32_t> src((size_t)h->Npad);
+        HIP_TRY(h, hipMemcpyAsync(src.data(), h->d_src + (size_t)e * h->Npad, src.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (counts_p) std::fill(counts_p, counts_p + L, 0);
+        if (counts_m) std::fill(counts_m, counts_m + L, 0);
+        for (uint32_t w : src) {
+            if (w & DEAD_BIT) continue;
+            if (w & SPIN_BIT) { if (counts_p) counts_p[w & POS_MASK]++; }
+            else if (counts_m) counts_m[w & POS_MASK]++;
+        }
+    }
+    if (m_field) {
+        int rc = launch_field(h, e, h->d_src + (size_t)e * h->Npad, h->d_bounds + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return APS_OK;
+}
+
+int aps_field_from_counts(aps_handle *h, int32_t e, const int64_t *counts_p, const int64_t *counts_m, double *m_field) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !counts_p || !counts_m || !m_field) return fail(h, APS_ERR_ARG, "aps_field_from_counts: bad argument");
+    const int L = h->p.L;
+    std::vector<uint32_t> src;
+    long long gs[2] = {0, 0};
+    for (int x = 0; x < L; ++x) {
+        if (counts_p[x] < 0 || counts_m[x] < 0) return fail(h, APS_ERR_ARG, "aps_field_from_counts: negative count");
+        for (int64_t k = 0; k < counts_p[x]; ++k) src.push_back((uint32_t)x | SPIN_BIT);
+        for (int64_t k = 0; k < counts_m[x]; ++k) src.push_back((uint32_t)x);
+        gs[0] += counts_p[x] - counts_m[x]; gs[1] += counts_p[x] + counts_m[x];
+    }
+    if (gs[1] > (long long)4 * h->p.K * L) return fail(h, APS_ERR_ARG, "aps_field_from_counts: more than 4*K*L particles would break the exact-sum bound");
+    const size_t nt = (src.size() + TILE - 1) / TILE + 1;
+    src.resize(nt * TILE, DEAD_BIT);
+    std::vector<int2> bounds(nt, make_int2(0x7fffffff, -1));
+    for (size_t s = 0; s < src.size(); ++s) {
+        if (src[s] & DEAD_BIT) continue;
+        const int p = (int)(src[s] & POS_MASK);
+        bounds[s / TILE].x = std::min(bounds[s / TILE].x, p); bounds[s / TILE].y = std::max(bounds[s / TILE].y, p);
+    }
+    if (nt > h->tmp_cap) {
+        if (h->d_tmp_src) { (void)hipFree(h->d_tmp_src); (void)hipFree(h->d_tmp_bounds); h->d_tmp_src = nullptr; h->d_tmp_bounds = nullptr; }
+        int rc;
+        if ((rc = dev_alloc(h, &h->d_tmp_src, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_bounds, nt))) return rc;
+        h->tmp_cap = nt;
+    }
+    long long saved[2];
+    HIP_TRY(h, hipMemcpyAsync(saved, h->d_gsum + 2 * e, sizeof(saved), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_src, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_bounds, bounds.data(), bounds.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gs, sizeof(gs), hipMemcpyHostToDevice, h->stream));
+    int rc = launch_field(h, e, h->d_tmp_src, h->d_tmp_bounds, (int)nt, h->d_mfield);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, saved, sizeof(saved), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+}  // extern "C"

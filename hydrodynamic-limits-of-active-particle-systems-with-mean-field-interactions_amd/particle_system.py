@@ -1,0 +1,218 @@
+"""`ParticleSystem` -- the reference's solver class (PARTICLE_solver_CLASS.py:13) re-hosted on the
+MI355X stepper.  Same constructor keywords (ref :16-39), same attributes, same `run()` result
+dictionary (ref :542-557); the time loop runs in HIP kernels behind the C ABI of include/aps.h.
+
+Differences that are part of the design:
+  * time advances in fixed steps `dt` (synchronous scheme) instead of one Gillespie event at a time;
+    `dt` defaults to 0.1 / (largest possible total rate of one particle);
+  * randomness inside `run` comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng` right
+    after the initial condition, so a seeded `rng` still makes the whole run reproducible);
+  * `flip_rate_fn` must stay None (the Curie-Weiss rate exp(-beta*sigma*m) is evaluated on the GPU).
+There is no CPU fallback: without libaps_hip.so or without a GPU, construction of the stepper raises.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import capi
+
+
+class ParticleSystem:
+    def __init__(self, L, xlim, rate_diffusion, rate_active, beta, flip_rate_fn=None, init="fixed",
+                 N=1000, rho0_plus=None, rho0_minus=None, rng=None, scale_rates=True,
+                 local_kernel_sigma=0.005, periodic=False, minus_anchor=True,
+                 immobilize_when_anchored=True, anchor_positions=None, anchor_radius=0.005,
+                 site_capacity=1, crowding_suppresses_rates=False, k_on=0.1, k_off=0.01,
+                 suppress_flip_when_bound=True, k_exit=0,
+                 # extensions (all optional, after the reference's keywords)
+                 dt=None, seed=None, device=0, sort_by_site=True):
+        self.L = int(L)
+        self.xlim = xlim
+        self.K = int(site_capacity)
+        self.dx = self.xlim / self.L
+        if scale_rates:                                            # ref :45-50
+            self.rate_diffusion = rate_diffusion / (self.dx ** 2)
+            self.rate_active = rate_active / self.dx
+        else:
+            self.rate_diffusion = float(rate_diffusion)
+            self.rate_active = float(rate_active)
+        self.beta = beta
+        self.k_on, self.k_off, self.k_exit = k_on, k_off, k_exit
+        self.suppress_flip_when_bound = suppress_flip_when_bound
+        self.crowding_suppresses_rates = crowding_suppresses_rates
+        if flip_rate_fn is not None:
+            raise NotImplementedError(
+                "flip_rate_fn: only the default Curie-Weiss rate exp(-beta*sigma*m) runs on the GPU path")
+        self.flip_rate_fn = None
+        assert init in ("fixed", "poisson")
+        self.init_mode = init
+        if init == "fixed":
+            if float(N) != int(N):
+                raise ValueError("N must be integral")
+            self.N_fixed = int(N)
+        else:
+            self.rho0_plus = np.array([rho0_plus(i / self.L) for i in range(self.L)], dtype=float)
+            self.rho0_minus = np.array([rho0_minus(i / self.L) for i in range(self.L)], dtype=float)
+        self.rng = np.random.default_rng() if rng is None else rng
+        self.local_kernel_sigma = local_kernel_sigma
+        self.periodic = periodic
+        self.immobilize_when_anchored = immobilize_when_anchored
+        self.minus_anchor = minus_anchor
+        self._sigma_grid = self.local_kernel_sigma / self.dx
+        self.anchor_radius = anchor_radius
+        self.anchor_positions = anchor_positions
+        self.is_anchor_site = np.zeros(self.L, dtype=bool)
+        if anchor_positions is None:
+            self.anchor_idxs = np.array([], dtype=int)
+            self.anchor_idx_array = np.array([], dtype=int)
+        else:                                                      # ref :93-104
+            centres = np.unique(np.round((np.asarray(anchor_positions, dtype=float) / self.xlim)
+                                         * (self.L - 1)).astype(int))
+            self.anchor_idxs = centres
+            reach = int(np.ceil(anchor_radius / self.dx))
+            for c in centres:
+                self.is_anchor_site[max(0, c - reach):min(self.L - 1, c + reach) + 1] = True
+            self.anchor_idx_array = np.flatnonzero(self.is_anchor_site)
+        # stepper extensions
+        self.dt = None if dt is None else float(dt)
+        self.seed = seed
+        self.device = int(device)
+        self.sort_by_site = bool(sort_by_site)
+        self._handle = None
+
+    # ------------------------------------------------------------------ initial conditions (host)
+    def _init_fixed(self):
+        N, L, K = self.N_fixed, self.L, self.K
+        if K == 1:                                                 # ref :144-147
+            sites = self.rng.choice(L, size=N, replace=False)
+        else:                                                      # ref :149-156, one draw per particle
+            sites = np.empty(N, dtype=np.int64)
+            fill = np.zeros(L, dtype=int)
+            for k in range(N):
+                sites[k] = self.rng.choice(np.flatnonzero(fill < K))
+                fill[sites[k]] += 1
+        spins = self.rng.choice([1, -1], size=N)
+        return sites.astype(np.int64), spins.astype(np.int8)
+
+    def _init_poisson(self):
+        plus = self.rng.poisson(self.rho0_plus)                    # ref :161-162
+        minus = self.rng.poisson(self.rho0_minus)
+        sites, spins = [], []
+        for x in np.flatnonzero(plus + minus):
+            kinds = np.array([1] * int(plus[x]) + [-1] * int(minus[x]), dtype=int)
+            if len(kinds) > self.K:                                # ref :174-176
+                kinds = kinds[self.rng.choice(len(kinds), size=self.K, replace=False)]
+            sites += [x] * len(kinds)
+            spins += kinds.tolist()
+        return np.array(sites, dtype=np.int64), np.array(spins, dtype=np.int8)
+
+    def init_particles(self):
+        return self._init_fixed() if self.init_mode == "fixed" else self._init_poisson()
+
+    @staticmethod
+    def empirical_densities_from_particles(pos, sigma, L, dx, total_norm=None):
+        cp = np.bincount(pos[sigma == 1], minlength=L)
+        cm = np.bincount(pos[sigma == -1], minlength=L)
+        denom = float(max(1, pos.size) if total_norm is None else total_norm) * dx
+        return (cp / denom).astype(float), (cm / denom).astype(float)
+
+    # ------------------------------------------------------------------ stepper plumbing
+    def default_dt(self):
+        """0.1 / (upper bound of one particle's total rate): max_i r_i * dt <= 0.1."""
+        rmax = (2.0 * self.rate_diffusion + self.rate_active + math.exp(abs(self.beta))
+                + max(self.k_on, self.k_off) + self.k_exit)
+        return 0.1 / rmax
+
+    def _make_handle(self, n_particles, seed):
+        if self.dt is None:
+            self.dt = self.default_dt()
+        return capi.Handle(
+            L=self.L, K=self.K, periodic=self.periodic, sigma_grid=self._sigma_grid,
+            rate_diffusion=self.rate_diffusion, rate_active=self.rate_active, beta=[float(self.beta)],
+            dt=self.dt, seed=seed, n_particles=n_particles, minus_anchor=self.minus_anchor,
+            immobilize=self.immobilize_when_anchored, suppress_flip=self.suppress_flip_when_bound,
+            crowding=self.crowding_suppresses_rates, k_on=self.k_on, k_off=self.k_off, k_exit=self.k_exit,
+            anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site)
+
+    def compute_local_m_field(self, counts_p, counts_m):
+        """m-field on all L sites for given site histograms (ref :216-246), evaluated on the GPU."""
+        h = self._handle or self._make_handle(1, 0)
+        try:
+            return h.field_from_counts(counts_p, counts_m)
+        finally:
+            if h is not self._handle:
+                h.close()
+
+    def step_gillespie(self, *args, **kwargs):
+        raise NotImplementedError(
+            "step_gillespie (one exact Gillespie event, ref :254-448) is not part of the GPU path; "
+            "run() advances all particles synchronously with step dt")
+
+    # ------------------------------------------------------------------ run (ref :450-558)
+    def run(self, T=10.0, obs_dt=0.01, record_fft=False, record_var=False):
+        L, dx = self.L, self.dx
+        pos0, sigma0 = self.init_particles()
+        n0 = len(pos0)
+        seed = self.seed if self.seed is not None else int(self.rng.integers(0, 2 ** 63))
+        self.seed_used = seed
+        h = self._handle = self._make_handle(max(n0, 1), seed)
+        try:
+            h.set_state(pos0, sigma0)
+            times_obs = np.arange(0.0, T, obs_dt)
+            M = len(times_obs)
+            pos_list, particle_count_list, bound_list = [None] * M, [None] * M, [None] * M
+            rho_p_list, rho_m_list = np.zeros((M, L)), np.zeros((M, L))
+            total_list, m_local_list = np.zeros((M, L)), np.zeros((M, L))
+            m_global = np.zeros(M)
+            rho_hat_complex = np.zeros((M, L), dtype=complex) if record_fft else None
+            fft_amp_list = np.zeros((M, L)) if record_fft else None
+            var_list = np.zeros(M) if record_var else None
+            done_steps = 0
+            for k in range(M):
+                # smallest step count whose time k*dt reaches the observation time (ref :517)
+                want = int(math.ceil(times_obs[k] / self.dt - 1e-9))
+                if want > done_steps:
+                    h.step(want - done_steps)
+                    done_steps = want
+                pos, sigma, bound, alive = h.get_state()
+                live = alive.astype(bool)
+                p, s = pos[live].astype(np.int64), sigma[live]
+                pos_list[k] = p
+                rho_p, rho_m = self.empirical_densities_from_particles(p, s, L, dx)
+                rho_p_list[k], rho_m_list[k], total_list[k] = rho_p, rho_m, rho_p + rho_m
+                particle_count_list[k] = p.size
+                bound_list[k] = bound[live].astype(bool)
+                m_local_list[k] = h.observe(want_field=True)[2]
+                m_global[k] = np.mean(s) if s.size else np.nan
+                if record_fft:
+                    u = total_list[k]
+                    spec = np.fft.fft(u)
+                    rho_hat_complex[k], fft_amp_list[k] = spec, np.abs(spec)
+                    if record_var:                      # kept only together with the FFT (ref :499-507)
+                        var_list[k] = float(np.var(u))
+                h.resort()
+            ex = h.exits()
+            self.steps_done = done_steps
+        finally:
+            h.close()
+            self._handle = None
+        return {
+            "times_obs": times_obs, "pos_list": pos_list, "rho_p_list": rho_p_list,
+            "rho_m_list": rho_m_list, "total_list": total_list,
+            "particle_count_list": particle_count_list, "bound_list": bound_list,
+            "m_local_list": m_local_list, "m_global": m_global, "rho_hat_complex": rho_hat_complex,
+            "fft_amp_list": fft_amp_list, "var_list": var_list,
+            "exit_times": [float(t) for t in ex[:, 0]], "exit_positions": [int(x) for x in ex[:, 1]],
+        }
+
+    # ------------------------------------------------------------------ the one plotting method a driver uses
+    def plot_individuals(self, out, show_k_max=6, cmap_name="viridis", xlim=1, fig_size=(10, 6)):
+        """Returns mean_v_eff like the reference (ref :901-906, :978); the PNG output of the
+        reference's method is presentation code and is not reproduced."""
+        total = out["total_list"]
+        grid = np.linspace(0, 1.0, self.L)
+        com = (total * grid).sum(axis=1) / (total.sum(axis=1) + 1e-12)
+        v_eff = np.gradient(com, out["times_obs"])
+        return np.mean(v_eff[int(len(v_eff) * 0.6):])

@@ -1,0 +1,119 @@
+/* aps.h -- C ABI of the MI355X-native active-particle stepper (libaps_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of the reference's ParticleSystem
+ * (PARTICLE_solver_CLASS.py): plain C types, caller-allocated host buffers, an opaque handle.
+ * The Python face `ParticleSystem` (package file particle_system.py) binds it with ctypes; the
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Each entry point names the reference code it replaces (file = PARTICLE_solver_CLASS.py).
+ * All functions return 0 on success and a negative code on failure; aps_last_error() gives the text.
+ * A handle is not thread-safe; different handles may be used from different threads.
+ */
+#ifndef APS_H
+#define APS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APS_OK 0
+#define APS_ERR_ARG (-1)      /* bad argument / unsupported parameter combination */
+#define APS_ERR_HIP (-2)      /* a HIP runtime call failed (text in aps_last_error) */
+#define APS_ERR_STATE (-3)    /* call not valid in the current state (e.g. no state uploaded) */
+#define APS_ERR_NODEVICE (-4) /* no usable GPU */
+
+typedef struct aps_handle aps_handle;
+
+/* Mirrors the reference constructor keywords (ref :14-138) after the rate scaling of :45-50.
+ * One handle carries n_ensembles independent systems of the same shape (BASELINE config 4). */
+typedef struct aps_params {
+    int32_t L;                  /* lattice sites, 2 <= L <= 2^25                     ref :41 */
+    int32_t K;                  /* site capacity, 1..32                              ref :43 */
+    int32_t periodic;           /* 0 = reflecting walls, 1 = torus                   ref :81 */
+    int32_t minus_anchor;       /*                                                   ref :83 */
+    int32_t immobilize;         /* immobilize_when_anchored                          ref :82 */
+    int32_t suppress_flip;      /* suppress_flip_when_bound                          ref :54 */
+    int32_t crowding;           /* crowding_suppresses_rates                         ref :55 */
+    int32_t n_ensembles;        /* >= 1 */
+    int64_t n_particles;        /* particles per ensemble (capacity of the state arrays) */
+    double sigma_grid;          /* local_kernel_sigma / dx; <= 0 selects the global mean   ref :84, :219 */
+    double rate_diffusion;      /* scaled                                            ref :45-50 */
+    double rate_active;
+    double k_on, k_off, k_exit; /*                                                   ref :52-56 */
+    double dt;                  /* fixed step of the synchronous scheme */
+    uint64_t seed;              /* Philox key */
+    const double *beta;         /* [n_ensembles]                                     ref :51 */
+    const uint8_t *anchor_mask; /* [L] is_anchor_site, or NULL for none              ref :88-104 */
+    int32_t device;             /* HIP device ordinal */
+    int32_t rank, world;        /* particle-index shard of this handle (world = 1: everything) */
+    int32_t sort_by_site;       /* 1: keep particles ordered by site internally (tile culling) */
+    int32_t ensemble_base;      /* Philox counter word 3 of local ensemble e is ensemble_base + e */
+    int32_t reserved[3];
+} aps_params;
+
+int aps_device_count(void);
+const char *aps_last_error(const aps_handle *h);   /* h may be NULL: error of the last failed aps_create */
+
+/* replaces ParticleSystem.__init__ (ref :14-138): builds the weight table, allocates device state */
+int aps_create(const aps_params *p, aps_handle **out);
+void aps_destroy(aps_handle *h);
+
+/* Run subsequent launches on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
+int aps_set_stream(aps_handle *h, void *hip_stream);
+
+/* State exchange in ORIGINAL particle order (the order init_particles returned, ref :191-195).
+ * sigma is +1/-1, bound and alive are 0/1; alive may be NULL (= all alive). n <= n_particles. */
+int aps_set_state(aps_handle *h, int32_t ensemble, const int32_t *pos, const int8_t *sigma,
+                  const uint8_t *bound, const uint8_t *alive, int64_t n);
+int aps_get_state(aps_handle *h, int32_t ensemble, int32_t *pos, int8_t *sigma, uint8_t *bound,
+                  uint8_t *alive, int64_t n);
+
+/* Parity hook for the all-pairs kernel: per particle S = sum sigma_j w(d_ij), W = sum w(d_ij)
+ * (ref :216-246 in all-pairs form) and occ4 = occupancy of {own, forward, left, right} target site
+ * (ref :294-301).  Arrays are [n] / [n] / [4n] in original order. */
+int aps_pair_accumulate(aps_handle *h, int32_t ensemble, double *S, double *W, int32_t *occ4, int64_t n);
+
+/* replaces the body of the `while t < T` loop (ref :511-516): nsteps synchronous steps of dt. */
+int aps_step(aps_handle *h, int64_t nsteps);
+
+/* The two halves of one step, for callers that exchange proposals between ranks themselves:
+ * aps_propose fills this rank's block of the proposal buffer, aps_commit applies ALL blocks. */
+int aps_propose(aps_handle *h);
+int aps_commit(aps_handle *h);
+/* Device address/size of the whole proposal buffer and of this rank's block inside it. */
+int aps_exchange_buffer(aps_handle *h, void **dev_ptr, int64_t *total_bytes, int64_t *my_offset,
+                        int64_t *my_bytes);
+
+/* Use caller-owned device memory (>= total_bytes of aps_exchange_buffer) as the proposal buffer, e.g. a
+ * torch tensor that torch.distributed all-gathers in place.  NULL returns to the internal buffer. */
+int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes);
+
+/* replaces the observation block (ref :517-536): site histograms and the m-field on all L sites. */
+int aps_observe(aps_handle *h, int32_t ensemble, int64_t *counts_p, int64_t *counts_m, double *m_field);
+
+/* m-field for a caller-supplied histogram: compute_local_m_field(counts_p, counts_m) (ref :216-246) */
+int aps_field_from_counts(aps_handle *h, int32_t ensemble, const int64_t *counts_p, const int64_t *counts_m,
+                          double *m_field);
+
+int aps_time(aps_handle *h, double *t, int64_t *step_index);
+
+/* Exit log (ref :424-436): rows of (time, position, particle index), ordered by (time, index). */
+int aps_get_exits(aps_handle *h, int32_t ensemble, double *rows3, int64_t cap_rows, int64_t *n_rows);
+
+/* Weight table actually used by the kernels (for parity tests): entries, and the grid exponent q. */
+int aps_get_table(aps_handle *h, double *out, int32_t cap, int32_t *tlen, int32_t *q);
+
+/* Re-establish the site-sorted internal order (no effect on results; speeds up tile culling). */
+int aps_resort(aps_handle *h);
+
+/* Measurement: run nsteps steps with HIP events around every launch of the all-pairs kernel on the
+ * handle's stream; returns their summed duration, the number of launches and pair evaluations. */
+int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_t *launches,
+                   double *pairs_evaluated);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APS_H */

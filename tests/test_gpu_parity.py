@@ -1,0 +1,277 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bars (DESIGN.md "Parity"):
+  weight table, S, W, occ4, m-field .... bit-exact vs oracle/sync_oracle.c (sums are exact on the 2^-q grid)
+  integer state (pos, sigma, bound, alive) after every step .... bit-exact vs the oracle
+  m-field vs the REFERENCE fixture G1 .... <= 2e-11 (weight-grid rounding, same bound as the oracle's)
+The oracle uses the lattice formulation (histogram + windowed stencil), the GPU the all-pairs one."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle.gillespie_numpy import LatticeGasParams
+from oracle import sync_oracle as so
+
+pytestmark = pytest.mark.gpu
+PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
+
+
+@pytest.fixture(scope="module")
+def capi():
+    mod = importlib.import_module(PKG + ".capi")
+    assert mod.device_count() >= 1, "no GPU visible"
+    return mod
+
+
+def make_handle(capi, par, n, dt=0.05, seed=1, beta=None, **kw):
+    return capi.Handle(L=par.L, K=par.K, periodic=par.periodic, sigma_grid=par.sigma_grid if par.sigma_kernel > 0 else 0.0,
+                       rate_diffusion=par.rate_diffusion, rate_active=par.rate_active,
+                       beta=[par.beta] if beta is None else beta, dt=dt, seed=seed, n_particles=n,
+                       minus_anchor=par.minus_anchor, immobilize=par.immobilize_when_anchored,
+                       suppress_flip=par.suppress_flip_when_bound, crowding=par.crowding_suppresses_rates,
+                       k_on=par.k_on, k_off=par.k_off, k_exit=par.k_exit, anchor_mask=par.is_anchor_site, **kw)
+
+
+def random_state(rng, L, N, K):
+    slots = np.repeat(np.arange(L), K)
+    pos = rng.permutation(rng.choice(slots, size=N, replace=False)).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=N)
+    return pos, spin
+
+
+def params(L, K=1, sigma=0.02, periodic=False, **kw):
+    base = dict(xlim=1.0, rate_diffusion=0.6, rate_active=4.0, beta=1.1, scale_rates=False)
+    base.update(kw)
+    return LatticeGasParams.from_kwargs(L=L, local_kernel_sigma=sigma, periodic=periodic, site_capacity=K, **base)
+
+
+FIELD_CASES = [
+    dict(L=64, K=1, sigma=0.005), dict(L=64, K=3, sigma=0.3), dict(L=400, K=1, sigma=0.02),
+    dict(L=400, K=2, sigma=0.02, periodic=True), dict(L=1000, K=3, sigma=0.005, periodic=True),
+    dict(L=1000, K=1, sigma=0.3), dict(L=1000, K=1, sigma=0.0), dict(L=997, K=2, sigma=0.05),
+    dict(L=5000, K=1, sigma=0.005), dict(L=3000, K=1, sigma=0.2, periodic=True),
+]
+
+
+@pytest.mark.parametrize("case", FIELD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+@pytest.mark.parametrize("sort", [True, False], ids=["sorted", "unsorted"])
+def test_table_and_pair_sums_bit_exact(capi, case, sort):
+    par = params(**case)
+    rng = np.random.default_rng(42)
+    N = int(0.55 * par.L * par.K)
+    pos, spin = random_state(rng, par.L, N, par.K)
+    alive = (rng.random(N) > 0.1).astype(np.uint8)            # some dead particles must be inert
+    orc = so.SyncOracle(par, dt=0.05, seed=1)
+    orc.set_state(pos, spin, alive=alive)
+    h = make_handle(capi, par, N, sort_by_site=sort)
+    try:
+        tab, q = h.table()
+        if par.sigma_kernel > 0:
+            assert q == orc.q and np.array_equal(tab, orc.table)
+        h.set_state(pos, spin, alive=alive)
+        S, W, occ4 = h.pair_accumulate()
+        S0, W0, occ0 = orc.pair_sums()
+        assert np.array_equal(W, W0)
+        assert np.array_equal(S, S0)
+        assert np.array_equal(occ4, occ0)
+        cp, cm, m = h.observe()
+        cp0, cm0, m0 = orc.field_sites()
+        assert np.array_equal(cp, cp0) and np.array_equal(cm, cm0)
+        assert np.array_equal(m, m0)
+        # caller-supplied histogram path (compute_local_m_field)
+        assert np.array_equal(h.field_from_counts(cp0, cm0), m0)
+    finally:
+        h.close()
+
+
+def test_m_field_vs_reference_fixture(capi, golden):
+    g = golden("g1_mfield.npz")
+    base = g.meta["base_kw"]
+    worst = 0.0
+    for idx, c in enumerate(g.meta["cases"]):
+        par = LatticeGasParams.from_kwargs(L=c["L"], local_kernel_sigma=c["sigma"], periodic=c["periodic"],
+                                           site_capacity=c["K"], **base)
+        pos, sigma, want = g[f"c{idx}_pos"], g[f"c{idx}_sigma"], g[f"c{idx}_m"]
+        h = make_handle(capi, par, len(pos))
+        try:
+            h.set_state(pos, sigma)
+            m = h.observe()[2]
+        finally:
+            h.close()
+        if c["periodic"] and c["sigma"] > 0:
+            # the reference's FFT branch is round-off dominated where the Gaussian mass is tiny;
+            # weight the comparison by min(W, 1) exactly as tests/test_oracle_sync.py does
+            orc = so.SyncOracle(par, dt=0.05, seed=1)
+            orc.set_state(pos, sigma)
+            orc.field_sites()
+            wgt = np.minimum(orc.last_site_sums[1], 1.0)
+        else:
+            wgt = 1.0
+        err = np.max(np.abs(m - want) * wgt)
+        worst = max(worst, err)
+        assert err <= 2e-11, (c, err)
+    print("worst |m - m_ref| =", worst)
+
+
+STEP_CASES = [
+    dict(tag="k1_reflect", L=300, K=1, sigma=0.02, frac=0.5),
+    dict(tag="k1_periodic", L=300, K=1, sigma=0.03, periodic=True, frac=0.5),
+    dict(tag="k3_reflect_wide", L=200, K=3, sigma=0.3, frac=0.6),
+    dict(tag="k2_crowding", L=250, K=2, sigma=0.01, frac=0.7, crowding_suppresses_rates=True),
+    dict(tag="global_field", L=400, K=1, sigma=0.0, frac=0.45, beta=1.6),
+    dict(tag="anchors_exit", L=200, K=2, sigma=0.02, frac=0.5, anchor_positions=[0.3, 0.7], anchor_radius=0.08,
+         k_on=3.0, k_off=1.0, k_exit=2.0),
+    dict(tag="anchors_free_minus_periodic", L=200, K=2, sigma=0.02, frac=0.5, periodic=True, anchor_positions=[0.5],
+         anchor_radius=0.1, k_on=2.0, k_off=1.0, k_exit=1.0, minus_anchor=False, immobilize_when_anchored=False,
+         suppress_flip_when_bound=False),
+    dict(tag="dense_diffusive", L=128, K=1, sigma=0.05, frac=0.9, rate_diffusion=6.0),
+    dict(tag="tiny", L=2, K=1, sigma=0.0, frac=0.5, periodic=False),
+]
+
+
+@pytest.mark.parametrize("case", STEP_CASES, ids=lambda c: c["tag"])
+@pytest.mark.parametrize("sort", [True, False], ids=["sorted", "unsorted"])
+def test_trajectory_bit_exact_every_step(capi, case, sort):
+    case = dict(case)
+    tag, frac = case.pop("tag"), case.pop("frac")
+    par = params(**case)
+    rng = np.random.default_rng(7)
+    N = max(1, int(frac * par.L * par.K))
+    pos, spin = random_state(rng, par.L, N, par.K)
+    dt, seed = 0.04, 20260101
+    orc = so.SyncOracle(par, dt=dt, seed=seed)
+    orc.set_state(pos, spin)
+    h = make_handle(capi, par, N, dt=dt, seed=seed, sort_by_site=sort)
+    try:
+        h.set_state(pos, spin)
+        nsteps = 120
+        for s in range(nsteps):
+            orc.step()
+            h.step(1)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(al, orc.alive), (tag, s)
+            assert np.array_equal(p, orc.pos), (tag, s)
+            assert np.array_equal(sg, orc.spin), (tag, s)
+            assert np.array_equal(bd, orc.bound), (tag, s)
+            if s == 60:
+                h.resort()                      # re-sorting must not change anything observable
+        t, k = h.time()
+        assert k == nsteps and t == nsteps * dt
+        ex, ex0 = h.exits(), orc.exits()
+        assert len(ex) == len(ex0)
+        if len(ex0):
+            order = np.lexsort((ex0[:, 2], ex0[:, 0]))
+            assert np.array_equal(ex, ex0[order])
+        assert (np.bincount(p[al == 1], minlength=par.L).max() if al.any() else 0) <= par.K
+        assert not np.array_equal(p, pos) or N <= 1
+    finally:
+        h.close()
+
+
+def test_propose_commit_halves_equal_step(capi):
+    par = params(L=500, K=2, sigma=0.02)
+    rng = np.random.default_rng(3)
+    pos, spin = random_state(rng, 500, 600, 2)
+    a = make_handle(capi, par, 600, seed=5)
+    b = make_handle(capi, par, 600, seed=5)
+    try:
+        a.set_state(pos, spin)
+        b.set_state(pos, spin)
+        a.step(40)
+        for _ in range(40):
+            b.propose()
+            b.commit()
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert np.array_equal(x, y)
+        ptr, total, off, mine = b.exchange_buffer()
+        assert ptr and off == 0 and total == mine and mine >= 600
+    finally:
+        a.close()
+        b.close()
+
+
+def test_ensembles_are_independent_and_match_single_runs(capi):
+    """BASELINE config 4 shape: E ensembles with their own beta in one handle == E separate handles."""
+    par = params(L=400, K=1, sigma=0.02)
+    rng = np.random.default_rng(9)
+    betas = [0.0, 0.7, 1.5, 3.0]
+    states = [random_state(rng, 400, 180, 1) for _ in betas]
+    big = make_handle(capi, par, 180, seed=11, beta=betas)
+    try:
+        for e, (p, s) in enumerate(states):
+            big.set_state(p, s, ensemble=e)
+        big.step(60)
+        for e, (p, s) in enumerate(states):
+            one = make_handle(capi, par, 180, seed=11, beta=[betas[e]], ensemble_base=e)
+            orc_par = params(L=400, K=1, sigma=0.02, beta=betas[e])
+            orc = so.SyncOracle(orc_par, dt=0.05, seed=11, ensemble=e)
+            try:
+                one.set_state(p, s)
+                one.step(60)
+                orc.set_state(p, s)
+                orc.run(60)
+                got = big.get_state(ensemble=e)
+                for x, y in zip(got, one.get_state()):
+                    assert np.array_equal(x, y)
+                assert np.array_equal(got[0], orc.pos) and np.array_equal(got[1], orc.spin)
+            finally:
+                one.close()
+    finally:
+        big.close()
+
+
+def test_error_paths(capi):
+    par = params(L=100, K=1)
+    with pytest.raises(capi.ApsError):
+        make_handle(capi, par, 1000)                       # more particles than K*L
+    h = make_handle(capi, par, 10)
+    try:
+        with pytest.raises(capi.ApsError):
+            h.step(1)                                      # no state uploaded
+        with pytest.raises(capi.ApsError):
+            h.set_state(np.array([5, 5], np.int32), np.array([1, -1], np.int8))   # capacity exceeded
+        with pytest.raises(capi.ApsError):
+            h.set_state(np.array([100], np.int32), np.array([1], np.int8))        # outside the lattice
+        h.set_state(np.array([5, 6], np.int32), np.array([1, -1], np.int8))
+        h.step(3)
+    finally:
+        h.close()
+
+
+def test_full_size_properties(capi):
+    """BASELINE config 2 shape (N=1e5, L=2e5, K=1, sigma_g=1000): properties that need no oracle run:
+    exclusion, conservation, |dx| <= 1 per step, sorted == unsorted bit for bit, a spot check of
+    S/W against the oracle on a subset of targets via a small window state is covered elsewhere."""
+    L, N = 200_000, 100_000
+    par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7,
+                                       scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
+    rng = np.random.default_rng(0)
+    pos = rng.choice(L, size=N, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=N)
+    a = make_handle(capi, par, N, dt=0.0125, seed=0, sort_by_site=True)
+    b = make_handle(capi, par, N, dt=0.0125, seed=0, sort_by_site=False)
+    try:
+        a.set_state(pos, spin)
+        b.set_state(pos, spin)
+        # S and W at full size against the oracle (lattice formulation, ~1 s on the CPU)
+        orc = so.SyncOracle(par, dt=0.0125, seed=0)
+        orc.set_state(pos, spin)
+        S0, W0, occ0 = orc.pair_sums()
+        S, W, occ4 = a.pair_accumulate()
+        assert np.array_equal(S, S0) and np.array_equal(W, W0) and np.array_equal(occ4, occ0)
+        prev = pos.copy()
+        for _ in range(3):
+            a.step(5)
+            b.step(1); b.step(4)
+            pa, sa, ba, aa = a.get_state()
+            pb, sb, bb, ab = b.get_state()
+            assert np.array_equal(pa, pb) and np.array_equal(sa, sb)
+            assert aa.all() and np.bincount(pa, minlength=L).max() <= 1
+            assert np.abs(pa.astype(int) - prev).max() <= 5
+            prev = pa.astype(int)
+        orc.run(15)
+        assert np.array_equal(pa, orc.pos) and np.array_equal(sa, orc.spin)
+    finally:
+        a.close()
+        b.close()
