@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the synchronous stepper on BASELINE config 2.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (all-pairs sums -> rates -> Philox draw -> commit) over all N
+particles.  Workload: N=100000 particles on L=200000 sites, K=1, reflecting walls,
+sigma=0.005 (sigma_g=1000, 4001 taps), beta=0.7, rate_active=5, rate_diffusion=0.02, dt=0.0125,
+uniform-in-box synthetic initial condition, float64.  With --gpus N the particles are sharded by index
+(strong scaling of ONE system: the per-step all-gather carries 1 byte per particle).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
+
+WORK = dict(N=100_000, L=200_000, K=1, xlim=1.0, sigma=0.005, beta=0.7, rate_active=5.0, rate_diffusion=0.02,
+            dt=0.0125, seed=0)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
+
+
+def initial_state(w):
+    rng = np.random.default_rng(w["seed"])
+    pos = rng.choice(w["L"], size=w["N"], replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=w["N"])
+    return pos, spin
+
+
+def make_handle(capi, w, device=0, rank=0, world=1):
+    return capi.Handle(L=w["L"], K=w["K"], periodic=False, sigma_grid=w["sigma"] / (w["xlim"] / w["L"]),
+                       rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"], beta=[w["beta"]],
+                       dt=w["dt"], seed=w["seed"], n_particles=w["N"], device=device, rank=rank, world=world)
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """The oracle's C port of the same step, timed on one host core on a bounded sample."""
+    from oracle.gillespie_numpy import LatticeGasParams
+    from oracle import sync_oracle as so
+    par = LatticeGasParams.from_kwargs(L=w["L"], xlim=w["xlim"], rate_diffusion=w["rate_diffusion"],
+                                       rate_active=w["rate_active"], beta=w["beta"], scale_rates=False,
+                                       local_kernel_sigma=w["sigma"], site_capacity=w["K"])
+    orc = so.SyncOracle(par, dt=w["dt"], seed=w["seed"])
+    orc.set_state(*initial_state(w))
+    orc.run(1)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s and n < 50:
+        orc.run(1)
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": w["N"] * n / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} synchronous steps of the same N={w['N']} workload by oracle/sync_oracle.c "
+                      f"(lattice formulation, gcc -O2, 1 thread), {el:.1f} s"}
+
+
+def cpu_reference_loop(w, budget_s=12.0):
+    """The reference's own algorithm (one Gillespie event per iteration, NumPy) restated in
+    oracle/gillespie_numpy.py, on the same N and L: events/s and the equivalent particle-steps/s
+    (one event advances ONE particle; an event is worth 1/(mean rate * dt) particle-steps)."""
+    from oracle.gillespie_numpy import GillespieOracle
+    orc = GillespieOracle(L=w["L"], xlim=w["xlim"], rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"],
+                          beta=w["beta"], N=w["N"], scale_rates=False, local_kernel_sigma=w["sigma"],
+                          site_capacity=w["K"], rng=np.random.default_rng(w["seed"]))
+    pos, sigma = orc.init_particles()
+    bound = np.zeros(len(pos), bool)
+    cp = np.bincount(pos[sigma == 1], minlength=w["L"])
+    cm = np.bincount(pos[sigma == -1], minlength=w["L"])
+    t0 = time.perf_counter()
+    n, sim = 0, 0.0
+    while time.perf_counter() - t0 < budget_s and n < 200:
+        field = orc.mean_field(cp, cm)
+        pos, sigma, bound, tau = orc.fire_event(pos, sigma, bound, field, cp, cm, sim, ([], []))
+        sim += tau
+        n += 1
+    el = time.perf_counter() - t0
+    return {"events_per_s": n / el, "equiv_particle_steps_per_s": (sim * w["N"] / w["dt"]) / el, "cores": 1,
+            "sample": f"{n} Gillespie events (compute_local_m_field + step_gillespie restated in NumPy), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    w = dict(WORK)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    capi = importlib.import_module(PKG + ".capi")
+    if capi.device_count() < 1:
+        raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    pos, spin = initial_state(w)
+    roof = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        sharded = importlib.import_module(PKG + ".sharded")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        h = make_handle(capi, w, device=local_rank, rank=rank, world=world)
+        h.set_state(pos, spin)
+        stepper = sharded.ShardedStepper(sharded.HipEngine(h, torch.device("cuda", local_rank)))
+        stepper.step(args.warmup)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        stepper.step(args.steps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        # every rank must hold the same state; compare a checksum
+        p, s, b, a = h.get_state()
+        chk = torch.tensor([int(p.astype(np.int64).sum()), int((s > 0).sum())], dtype=torch.int64, device="cuda")
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert bool((lo == hi).all()), "ranks diverged"
+    else:
+        h = make_handle(capi, w)
+        h.set_state(pos, spin)
+        h.step(args.warmup)                       # aps_step synchronises its stream before returning
+        t0 = time.perf_counter()
+        h.step(args.steps)
+        elapsed = time.perf_counter() - t0
+        # dominant kernel, timed live with HIP events on the stream it is launched on
+        reps = max(10, min(args.steps, 50))
+        ms, launches, pairs = h.step_timed(reps)
+        avg_s = ms / launches * 1e-3
+        achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": "pair_propose", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"],
+                "note": "the all-pairs kernel is VALU/LDS-issue bound, not HBM bound (state is 0.4 MB); see valu",
+                "valu": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs / (ms * 1e-3),
+                         "lane_ops_per_pair": 10, "peak_lane_ops_per_s": VALU_LANE_OPS_PER_S,
+                         "frac": pairs / (ms * 1e-3) * 10 / VALU_LANE_OPS_PER_S}}
+    p, s, b, a = h.get_state()
+    assert a.all() and np.bincount(p, minlength=w["L"]).max() <= w["K"]
+    h.close()
+    if rank != 0:
+        return
+    out = {
+        "metric": "particle-steps/sec at N=1e5", "value": w["N"] * args.steps / elapsed, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
+                               "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on",
+                   "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"},
+    }
+    if roof:
+        out["roofline"] = roof
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w)
+        out["cpu_reference_loop"] = cpu_reference_loop(w)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
