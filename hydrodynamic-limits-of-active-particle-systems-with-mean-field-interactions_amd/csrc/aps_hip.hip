@@ -40,10 +40,21 @@ constexpr uint32_t SPIN_BIT = 1u << 27;
 constexpr uint32_t BOUND_BIT = 1u << 28;
 constexpr uint32_t DEAD_BIT = 1u << 29;
 constexpr uint32_t DEAD_P8 = POS_MASK << 3;   // far-away site (x8) every distance test rejects
+constexpr uint32_t SG_PLUS = 0x3FF00000u;     // high words of +1.0 / -1.0
+constexpr uint32_t SG_MINUS = 0xBFF00000u;
 constexpr int TILE = 64;                      // slots per tile = one wavefront of targets
-constexpr int WAVES = 4;                      // waves per workgroup; they split the source tiles
+#ifndef APS_WAVES
+#define APS_WAVES 4
+#endif
+constexpr int WAVES = APS_WAVES;              // waves per workgroup; they split the source tiles of one target tile
+constexpr int NTHREADS = TILE * WAVES;
+#ifndef APS_LIST_CAP
+#define APS_LIST_CAP 1024
+#endif
+constexpr int LIST_CAP = APS_LIST_CAP;        // active-tile work list entries per scan round
 
 enum { EV_NONE = 0, EV_LEFT = 1, EV_RIGHT = 2, EV_FWD = 3, EV_BIND = 4, EV_UNBIND = 5, EV_EXIT = 6, EV_FLIP = 7 };
+enum { V_FAST = 0, V_GENERIC = 1, V_MIRROR = 2 };
 
 // ---------------------------------------------------------------------------------------------
 // deterministic exp: mul, fma, rint and an exponent insert only -> identical bits on host and device
@@ -98,6 +109,7 @@ struct Model {               // by-value kernel argument: everything the rate co
 
 struct PairArgs {
     Model m;
+    const uint32_t *src;      // [E][Npad] packed state (epilogue reads the target's own word)
     const uint32_t *orig;     // [E][Npad]
     const long long *gsum;    // [E][2] sum of spins, number alive (global-field mode)
     const double *beta;       // [E]
@@ -107,80 +119,181 @@ struct PairArgs {
     double *S_out, *W_out;    // optional [E][Npad]
     int *occ4_out;            // optional [E][Npad][4]
     unsigned long long *tiles_done;   // statistics: source tiles actually evaluated
+    unsigned *work_ctr;       // next (ensemble, target tile) item; reset by apply()
+    unsigned long long *stamps;   // diagnostic build only (APS_STAMPS): per-workgroup phase cycle totals
     int tlen, Npad, SH, E, ntiles, tile_lo, tile_cnt;
     uint32_t step_lo, step_hi;
     int write_prop;
 };
 
-// |a - b| in one VALU op (the compiler expands __usad into min/max/sub).  b is wave-uniform (SGPR).
-__device__ __forceinline__ uint32_t absdiff_vs(uint32_t a_vec, uint32_t b_uni) {
+// ------------------------------------------------------------------------------------ inner loops
+// d = |a - b| + c in ONE VALU op.  b is wave-uniform (SGPR); c carries the LDS byte offset of the table,
+// so the result is directly the LDS address of w(|dp|).
+__device__ __forceinline__ uint32_t sad_vsv(uint32_t a_vec, uint32_t b_uni, uint32_t c_vec) {
     uint32_t d;
-    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a_vec), "s"(b_uni));
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a_vec), "s"(b_uni), "v"(c_vec));
     return d;
 }
 
-// One tile of 64 sources against this lane's target, in groups of 16.  The source words are
-// wave-uniform: they arrive by scalar loads (s_load_dwordx8/16) and are decoded on the scalar unit;
-// per pair the vector unit does |dp| (v_sad_u32), clamp, one LDS table read and two f64 accumulations.
-// Occupancy (same / neighbouring site) is rare, so the hot path only tracks the group's smallest
-// distance and the classification is redone under a per-group branch.
-template <int BC, bool MIRROR>
-__device__ __forceinline__ void tile_loop(const uint32_t *__restrict__ tile, const uint32_t pi8,
-                                          const double *__restrict__ tab, const uint32_t tlen8, const uint32_t L8,
-                                          double &accW, double &accS, int &c0, int &cl, int &cr) {
-    constexpr int G = 16;
-#pragma unroll 1
-    for (int g = 0; g < TILE; g += G) {
-        uint32_t w[G];
-        const uint4 *t4 = reinterpret_cast<const uint4 *>(tile + g);
+template <bool TAB_LDS>
+__device__ __forceinline__ double table_at(const double *__restrict__ table_g, uint32_t byte_addr) {
+    if (TAB_LDS) {
+        typedef __attribute__((address_space(3))) const double lds_cdouble;
+        return *reinterpret_cast<lds_cdouble *>(byte_addr);   // byte_addr already includes the table's LDS offset
+    }
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(table_g) + byte_addr);
+}
+
+// G sources (one scalar-loaded group) against this lane's target.  Sources arrive pre-decoded as
+// (site*8, high word of +-1.0) pairs through SCALAR loads (they are wave-uniform), so the scalar unit does
+// no per-source work; per pair the vector unit issues v_sad_u32 -> ds_read_b64 -> v_add_f64 -> v_fma_f64.
+//   V_FAST    every pair of the tile block is inside the table's reach and farther than one site: no clamp
+//   V_GENERIC clamp to the zero entry behind the table; track the smallest distance for the occupancy branch
+//   V_MIRROR  additionally the reflected images (distance p_i + p_j + 1 mod 2L)
+#ifndef APS_G
+#define APS_G 16
+#endif
+constexpr int G = APS_G;                      // sources per group (G/8 s_load_dwordx16)
+constexpr int NACC = 4;                       // independent accumulator chains (sums are exact: order-free)
+struct Group { uint4 v[G / 2]; };             // {p8, sg_hi, p8, sg_hi} x 4
+
+__device__ __forceinline__ Group load_group(const uint2 *__restrict__ p) {
+    Group g;
+#ifdef APS_ABL_NOSMEM               /* timing-only ablation: synthesise the sources, no memory read */
+    const uint32_t b = (uint32_t)(size_t)p;
 #pragma unroll
-        for (int k = 0; k < G / 4; ++k) {
-            const uint4 v = t4[k];
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        }
-        uint32_t near = 0xFFFFFFFFu;
+    for (int k = 0; k < G / 2; ++k) g.v[k] = make_uint4((b + 16u * k) & 0xFFFF8u, SG_PLUS, (b + 16u * k + 8u) & 0xFFFF8u, SG_MINUS);
+#else
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(p);
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const uint32_t pj8 = (w[k] & DEAD_BIT) ? DEAD_P8 : ((w[k] & POS_MASK) << 3);
-            const double sg = (w[k] & SPIN_BIT) ? 1.0 : -1.0;
-            const uint32_t d8 = absdiff_vs(pi8, pj8);
-            uint32_t t8 = d8;
-            if (BC == 1) t8 = min(d8, L8 - d8);              // circular distance on the torus
-            double wt = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + min(t8, tlen8));
-            if (MIRROR) {                                    // reflected images: distance p_i + p_j + 1 (mod 2L)
-                const uint32_t s8 = pi8 + pj8 + 8u;
-                const uint32_t m8 = min(min(s8, 2u * L8 - s8), tlen8);
-                wt += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + m8);
+    for (int k = 0; k < G / 2; ++k) g.v[k] = t4[k];
+#endif
+    return g;
+}
+
+template <int BC, int VAR, bool TAB_LDS>
+__device__ __forceinline__ void group_accumulate(const Group &grp, const uint32_t pi8, const uint32_t tbase,
+                                                 const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
+                                                 double (&accW)[NACC], double (&accS)[NACC], int &c0, int &cl, int &cr) {
+    uint32_t p8[G], sh[G];
+#pragma unroll
+    for (int k = 0; k < G / 2; ++k) {
+        p8[2 * k] = grp.v[k].x; sh[2 * k] = grp.v[k].y; p8[2 * k + 1] = grp.v[k].z; sh[2 * k + 1] = grp.v[k].w;
+    }
+    uint32_t near = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        double wt;
+        if (VAR == V_FAST) {
+#if defined(APS_ABL_NOLDS)          /* timing-only ablations (wrong results): no table read at all */
+            wt = (double)sad_vsv(pi8, p8[k], tbase);
+#elif defined(APS_ABL_NOCONFLICT)   /* table read at a conflict-free address */
+            wt = table_at<TAB_LDS>(table_g, (sad_vsv(pi8, p8[k], tbase) & 0u) + tbase + ((threadIdx.x & 63u) << 3));
+#else
+            wt = table_at<TAB_LDS>(table_g, sad_vsv(pi8, p8[k], tbase));
+#endif
+        } else {
+            const uint32_t d8 = sad_vsv(pi8, p8[k], 0u);
+            const uint32_t t8 = (BC == 1) ? min(d8, L8 - d8) : d8;      // circular distance on the torus
+            wt = table_at<TAB_LDS>(table_g, min(t8, tlen8) + tbase);
+            if (VAR == V_MIRROR) {
+                const uint32_t s8 = pi8 + p8[k] + 8u;
+                wt += table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
             }
-            accW += wt;
-            accS = fma(wt, sg, accS);
             near = min(near, t8);
         }
-        if (near <= 8u) {                                    // rare: same or neighbouring site -> occupancy
+        accW[k % NACC] += wt;
+#ifndef APS_ABL_NOFMA
+        accS[k % NACC] = fma(wt, __hiloint2double((int)sh[k], 0), accS[k % NACC]);
+#endif
+    }
+    if (VAR != V_FAST && near <= 8u) {                       // rare: same or neighbouring site -> occupancy
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                if (w[k] & DEAD_BIT) continue;
-                const int dlt = (int)((w[k] & POS_MASK) << 3) - (int)pi8;
-                c0 += (dlt == 0);
-                cr += (dlt == 8) | (BC == 1 && dlt == 8 - (int)L8);
-                cl += (dlt == -8) | (BC == 1 && dlt == (int)L8 - 8);
-            }
+        for (int k = 0; k < G; ++k) {
+            if (p8[k] == DEAD_P8) continue;
+            const int dlt = (int)p8[k] - (int)pi8;
+            c0 += (dlt == 0);
+            cr += (dlt == 8) | (BC == 1 && dlt == 8 - (int)L8);
+            cl += (dlt == -8) | (BC == 1 && dlt == (int)L8 - 8);
         }
     }
 }
 
-// Does any (target in [tlo,thi], source in [slo,shi]) pair fall inside the table's reach R?
+// Which loop variant (or none: -1) does the block (targets in [tlo,thi]) x (source tile info sb) need?
+// R = reach of the table in sites (>= 1 so that the occupancy of neighbouring sites is always seen).
 template <int BC>
-__device__ __forceinline__ void tile_tests(int tlo, int thi, int slo, int shi, int R, int L, bool &direct, bool &mirror) {
+__device__ __forceinline__ int tile_variant(int tlo, int thi, const int4 sb, int R, int Rtab, int L, bool allow_fast) {
+    if (sb.w <= 0) return -1;                                // no live particle in the tile
+    const int slo = sb.x, shi = sb.y;
     if (BC == 0) {
-        direct = (slo <= thi + R) && (shi >= tlo - R);
-        mirror = (tlo + slo + 1 <= R) || (2 * L - 1 - thi - shi <= R);
-    } else {
-        mirror = false;
-        const int lo = slo - thi, hi = shi - tlo;            // range of p_j - p_i
-        direct = (hi - lo >= L) || (lo <= R && hi >= -R) || (lo - L <= R && hi - L >= -R) ||
-                 (lo + L <= R && hi + L >= -R);
+        const bool direct = (slo <= thi + R) && (shi >= tlo - R);
+        const bool mirror = (tlo + slo + 1 <= R) || (2 * L - 1 - thi - shi <= R);
+        if (mirror) return V_MIRROR;
+        if (!direct) return -1;
+        const int far = max(thi - slo, shi - tlo);           // largest |p_i - p_j| in the block
+        const int gap = slo > thi ? slo - thi : (tlo > shi ? tlo - shi : 0);
+        return (allow_fast && far <= Rtab && gap >= 2 && sb.z == 0) ? V_FAST : V_GENERIC;
     }
+    const int lo = slo - thi, hi = shi - tlo;                // range of p_j - p_i
+    const bool direct = (hi - lo >= L) || (lo <= R && hi >= -R) || (lo - L <= R && hi - L >= -R) ||
+                        (lo + L <= R && hi + L >= -R);
+    return direct ? V_GENERIC : -1;
+}
+
+// Workgroup-cooperative accumulation for ONE tile of 64 targets (lane = target, every wave holds the same
+// targets).  All threads scan the tile-info array and append the source tiles that matter to a work list in
+// LDS; the waves then take list entries round-robin.  Returns this wave's partial sums.
+template <int BC, bool TAB_LDS>
+__device__ __forceinline__ unsigned accumulate_targets(const uint2 *__restrict__ spair_e, const int4 *__restrict__ tinfo_e,
+                                                       const int ntiles, const int tlo, const int thi, const bool allow_fast,
+                                                       const uint32_t pi8,
+                                                       const uint32_t tbase, const double *__restrict__ table_g,
+                                                       const int tlen, const int L, uint32_t *list, uint32_t *ctl,
+                                                       const int wave, double &accW_out, double &accS_out, int &c0, int &cl, int &cr) {
+    double accW[NACC], accS[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) accW[k] = accS[k] = 0.0;
+    const uint32_t tlen8 = (uint32_t)tlen << 3, L8 = (uint32_t)L << 3;
+    const int R = tlen > 1 ? tlen - 1 : 1, Rtab = tlen - 1;
+    unsigned done = 0;
+    for (int base = 0; base < ntiles; base += LIST_CAP) {
+        __syncthreads();                                     // previous round's list fully consumed
+        if (threadIdx.x == 0) ctl[1] = 0u;
+        __syncthreads();
+        const int end = min(base + LIST_CAP, ntiles);
+        for (int jt = base + (int)threadIdx.x; jt < end; jt += NTHREADS) {
+            const int var = tile_variant<BC>(tlo, thi, tinfo_e[jt], R, Rtab, L, allow_fast);
+            if (var >= 0) list[atomicAdd(&ctl[1], 1u)] = (uint32_t)jt | ((uint32_t)var << 28);
+        }
+        __syncthreads();
+        const int n = (int)ctl[1];
+#ifdef APS_ABL_NOACC
+        if (n >= 0) continue;
+#endif
+        for (int i = wave; i < n; i += WAVES) {
+            const uint32_t ent = __builtin_amdgcn_readfirstlane(list[i]);
+            const uint2 *__restrict__ tile = spair_e + (size_t)(ent & 0x0FFFFFFFu) * TILE;
+            const uint32_t var = ent >> 28;
+#pragma unroll 1
+            for (int g = 0; g < TILE; g += G) {
+                const Group grp = load_group(tile + g);
+                if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS>(grp, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+                else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS>(grp, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+                else group_accumulate<BC, V_MIRROR, TAB_LDS>(grp, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+            }
+            ++done;
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < NACC; ++k) { accW[0] += accW[k]; accS[0] += accS[k]; }
+    accW_out += accW[0]; accS_out += accS[0];
+    return done;
+}
+
+// LDS carve-up shared by both kernels: [table (tlen+1) doubles][partials (WAVES-1)*64*4 doubles][list][ctl]
+__host__ __device__ inline size_t lds_table_doubles(int tlen, bool tab_lds) { return tab_lds ? (size_t)tlen + 1 : 0; }
+__host__ __device__ inline size_t lds_total_bytes(int tlen, bool tab_lds) {
+    return (lds_table_doubles(tlen, tab_lds) + (size_t)(WAVES - 1) * TILE * 4) * sizeof(double) + (LIST_CAP + 4) * sizeof(uint32_t);
 }
 
 struct Channels { double diff, act, flip, bind, unbind, leave, left, right, total; };
@@ -224,137 +337,159 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
     return c;
 }
 
-// The read-only arrays are separate `const __restrict__` kernel parameters (not struct members) so that
-// the compiler can prove the wave-uniform source reads are never clobbered and emit scalar loads.
+// Persistent workgroups: each pulls (ensemble, target tile) items from an atomic counter, so the weight
+// table is staged into LDS once per workgroup and the grid has no tail.  The read-only arrays are separate
+// `const __restrict__` kernel parameters (not struct members) so the compiler can prove the wave-uniform
+// source reads are never clobbered and emits scalar loads for them.
 template <int BC, bool TAB_LDS>
-__global__ __launch_bounds__(TILE *WAVES) void pair_propose(const PairArgs a, const uint32_t *__restrict__ src_all,
-                                                           const int2 *__restrict__ bounds_all,
-                                                           const double *__restrict__ table_g) {
+__global__ __launch_bounds__(NTHREADS) void pair_propose(const PairArgs a, const uint2 *__restrict__ spair_all,
+                                                        const int4 *__restrict__ tinfo_all,
+                                                        const double *__restrict__ table_g) {
     extern __shared__ double lds[];
     const Model &M = a.m;
-    const int e = blockIdx.y;
-    const int ttile = a.tile_lo + blockIdx.x;
     const int lane = threadIdx.x & (TILE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // the commit that follows this launch needs empty per-site proposer counters
     {
         const size_t total = (size_t)a.E * (size_t)M.L;
-        const size_t nthreads = (size_t)gridDim.x * gridDim.y * blockDim.x;
-        const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        for (size_t i = gtid; i < total; i += nthreads) a.pcnt[i] = 0u;
+        const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) a.pcnt[i] = 0u;
     }
 
-    const double *tab = table_g;
-    double *part = lds;                                       // [WAVES][TILE][4] partial sums
+    const size_t tdoubles = lds_table_doubles(a.tlen, TAB_LDS);
+    double *part = lds + tdoubles;                            // [(WAVES-1)][TILE][4] partial sums
+    uint32_t *list = reinterpret_cast<uint32_t *>(part + (size_t)(WAVES - 1) * TILE * 4);
+    uint32_t *ctl = list + LIST_CAP;
+    uint32_t tbase = 0;
     if (TAB_LDS) {
-        for (int i = threadIdx.x; i <= a.tlen; i += TILE * WAVES) lds[i] = table_g[i];
-        tab = lds;
-        part = lds + (a.tlen + 1);
+        for (int i = threadIdx.x; i <= a.tlen; i += NTHREADS) lds[i] = table_g[i];
+        typedef __attribute__((address_space(3))) double lds_double;
+        tbase = (uint32_t)(size_t)(lds_double *)lds;          // LDS byte offset of the table
     }
-    __syncthreads();
+    const unsigned total_items = (unsigned)a.E * (unsigned)a.tile_cnt;
+#ifdef APS_STAMPS
+    unsigned long long t_fetch = 0, t_acc = 0, t_epi = 0, t_items = 0, t0 = __builtin_amdgcn_s_memtime(), t_start = t0;
+#define STAMP(var) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - t0; t0 = t1_; }
+#else
+#define STAMP(var)
+#endif
 
-    const uint32_t *__restrict__ src_e = src_all + (size_t)e * a.Npad;
-    const int2 *__restrict__ bounds_e = bounds_all + (size_t)e * a.ntiles;
-    const uint32_t me = src_e[(size_t)ttile * TILE + lane];
-    const uint32_t pi8 = (me & POS_MASK) << 3;
-    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)M.L << 3;
-    const int R = a.tlen > 1 ? a.tlen - 1 : 1;               // reach in sites (>= 1 for the occupancy test)
+    for (;;) {
+        __syncthreads();                                      // ctl[0] / partials of the previous item are consumed
+        if (threadIdx.x == 0) ctl[0] = atomicAdd(a.work_ctr, 1u);
+        __syncthreads();
+        const unsigned item = ctl[0];
+        STAMP(t_fetch)
+        if (item >= total_items) break;
+        const int e = (int)(item / (unsigned)a.tile_cnt);
+        const int ttile = a.tile_lo + (int)(item % (unsigned)a.tile_cnt);
+        const uint2 *__restrict__ spair_e = spair_all + (size_t)e * a.Npad;
+        const int4 *__restrict__ tinfo_e = tinfo_all + (size_t)e * a.ntiles;
+        const size_t slot = (size_t)ttile * TILE + lane;
+        const uint32_t pi8 = spair_e[slot].x == DEAD_P8 ? 0u : spair_e[slot].x;   // dead targets: any in-range site
+        const int4 tb = tinfo_e[ttile];
 
-    double accW = 0.0, accS = 0.0;
-    int c0 = 0, cl = 0, cr = 0;
-    unsigned done = 0;
-    const int2 tb = bounds_e[ttile];
-    if (tb.x <= tb.y) {
-        for (int jt = wave; jt < a.ntiles; jt += WAVES) {
-            const int2 sb = bounds_e[jt];
-            if (sb.x > sb.y) continue;                       // tile holds no live particle
-            bool direct, mirror;
-            tile_tests<BC>(tb.x, tb.y, sb.x, sb.y, R, M.L, direct, mirror);
-            if (!(direct || mirror)) continue;
-            const uint32_t *__restrict__ tile = src_e + (size_t)jt * TILE;
-            if (BC == 0 && mirror) tile_loop<BC, true>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
-            else tile_loop<BC, false>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
-            ++done;
+        double accW = 0.0, accS = 0.0;
+        int c0 = 0, cl = 0, cr = 0;
+        unsigned done = 0;
+        if (tb.w > 0)
+            done = accumulate_targets<BC, TAB_LDS>(spair_e, tinfo_e, a.ntiles, tb.x, tb.y, tb.z == 0, pi8, tbase, table_g, a.tlen, M.L,
+                                                   list, ctl, wave, accW, accS, c0, cl, cr);
+        if (lane == 0 && done && a.tiles_done) atomicAdd(a.tiles_done, (unsigned long long)done);
+        STAMP(t_acc)
+#ifdef APS_STAMPS
+        t_items += 1;
+#endif
+
+        // combine the waves' partial sums (exact on the weight grid, so the order is irrelevant)
+        if (wave != 0) {
+            double *mine = part + ((size_t)(wave - 1) * TILE + lane) * 4;
+            mine[0] = accW; mine[1] = accS;
+            reinterpret_cast<int *>(mine + 2)[0] = c0; reinterpret_cast<int *>(mine + 2)[1] = cl;
+            reinterpret_cast<int *>(mine + 3)[0] = cr;
         }
-    }
-    if (lane == 0 && done && a.tiles_done) atomicAdd(a.tiles_done, (unsigned long long)done);
-
-    // combine the four waves' partial sums (exact on the weight grid, so the order is irrelevant)
-    double *mine = part + ((size_t)wave * TILE + lane) * 4;
-    mine[0] = accW; mine[1] = accS;
-    reinterpret_cast<int *>(mine + 2)[0] = c0; reinterpret_cast<int *>(mine + 2)[1] = cl;
-    reinterpret_cast<int *>(mine + 3)[0] = cr;
-    __syncthreads();
-    if (wave != 0) return;
-    for (int w = 1; w < WAVES; ++w) {
-        const double *o = part + ((size_t)w * TILE + lane) * 4;
-        accW += o[0]; accS += o[1];
-        c0 += reinterpret_cast<const int *>(o + 2)[0]; cl += reinterpret_cast<const int *>(o + 2)[1];
-        cr += reinterpret_cast<const int *>(o + 3)[0];
-    }
-
-    // ---------------- epilogue: one lane = one target particle
-    const size_t slot = (size_t)ttile * TILE + lane;
-    const bool live = !(me & DEAD_BIT);
-    const int p = (int)(me & POS_MASK);
-    const int spin = (me & SPIN_BIT) ? 1 : -1;
-    const bool bound = (me & BOUND_BIT) != 0;
-    if (M.field_mode == 0) {                                  // global mean field (ref :219-221)
-        accS = (double)a.gsum[2 * e]; accW = (double)a.gsum[2 * e + 1];
-    }
-    if (!live) { accS = 0.0; accW = 0.0; c0 = cl = cr = 0; }
-    const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == M.L - 1;
-    if (a.S_out) {
-        a.S_out[(size_t)e * a.Npad + slot] = accS;
-        a.W_out[(size_t)e * a.Npad + slot] = accW;
-        int *o = a.occ4_out + ((size_t)e * a.Npad + slot) * 4;
-        const int o_l = wall_l ? c0 : cl, o_r = wall_r ? c0 : cr;
-        o[0] = c0; o[1] = live ? (spin > 0 ? o_r : c0) : 0; o[2] = live ? o_l : 0; o[3] = live ? o_r : 0;
-    }
-    if (!a.write_prop) return;
-    uint8_t code = EV_NONE;
-    if (live) {
-        double mloc = 0.0;
-        if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
-        const bool anch = a.anchor ? a.anchor[p] != 0 : false;
-        const Channels c = channels(M, anch, p, spin, bound, mloc, a.beta[e], c0, cl, cr);
-        uint32_t x[4];
-        philox4x32_10(a.step_lo, a.step_hi, a.orig[(size_t)e * a.Npad + slot], (uint32_t)(M.ens_base + e),
-                      M.seed_lo, M.seed_hi, x);
-        const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
-        const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
-        const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
-        if (u0 < p_fire) {
-            const double v = u1 * c.total;
-            const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
-                         e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
-            int ev = EV_NONE, occ_t = 0;
-            if (v < e_diff) {
-                if (c.left + c.right > 0.0) {
-                    if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
-                    else { ev = EV_RIGHT; occ_t = cr; }
-                }
-            } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
-            else if (v < e_bind) ev = EV_BIND;
-            else if (v < e_unbind) ev = EV_UNBIND;
-            else if (v < e_exit) ev = EV_EXIT;
-            else ev = EV_FLIP;
-            int cap = M.K - occ_t;                           // free capacity of the hop target at step start
-            cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
-            code = (uint8_t)(ev | ((cap - 1) << 3));
+        __syncthreads();
+        if (wave != 0) continue;
+        for (int w = 0; w < WAVES - 1; ++w) {
+            const double *o = part + ((size_t)w * TILE + lane) * 4;
+            accW += o[0]; accS += o[1];
+            c0 += reinterpret_cast<const int *>(o + 2)[0]; cl += reinterpret_cast<const int *>(o + 2)[1];
+            cr += reinterpret_cast<const int *>(o + 3)[0];
         }
+
+        // ---------------- epilogue: one lane = one target particle
+        const uint32_t me = a.src[(size_t)e * a.Npad + slot];
+        const bool live = !(me & DEAD_BIT);
+        const int p = (int)(me & POS_MASK);
+        const int spin = (me & SPIN_BIT) ? 1 : -1;
+        const bool bound = (me & BOUND_BIT) != 0;
+        if (M.field_mode == 0) {                              // global mean field (ref :219-221)
+            accS = (double)a.gsum[2 * e]; accW = (double)a.gsum[2 * e + 1];
+        }
+        if (!live) { accS = 0.0; accW = 0.0; c0 = cl = cr = 0; }
+        const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == M.L - 1;
+        if (a.S_out) {
+            a.S_out[(size_t)e * a.Npad + slot] = accS;
+            a.W_out[(size_t)e * a.Npad + slot] = accW;
+            int *o = a.occ4_out + ((size_t)e * a.Npad + slot) * 4;
+            const int o_l = wall_l ? c0 : cl, o_r = wall_r ? c0 : cr;
+            o[0] = c0; o[1] = live ? (spin > 0 ? o_r : c0) : 0; o[2] = live ? o_l : 0; o[3] = live ? o_r : 0;
+        }
+        if (!a.write_prop) continue;
+        uint8_t code = EV_NONE;
+        if (live) {
+            double mloc = 0.0;
+            if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+            const bool anch = a.anchor ? a.anchor[p] != 0 : false;
+            const Channels c = channels(M, anch, p, spin, bound, mloc, a.beta[e], c0, cl, cr);
+            uint32_t x[4];
+            philox4x32_10(a.step_lo, a.step_hi, a.orig[(size_t)e * a.Npad + slot], (uint32_t)(M.ens_base + e),
+                          M.seed_lo, M.seed_hi, x);
+            const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
+            const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
+            const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
+            if (u0 < p_fire) {
+                const double v = u1 * c.total;
+                const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
+                             e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
+                int ev = EV_NONE, occ_t = 0;
+                if (v < e_diff) {
+                    if (c.left + c.right > 0.0) {
+                        if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
+                        else { ev = EV_RIGHT; occ_t = cr; }
+                    }
+                } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
+                else if (v < e_bind) ev = EV_BIND;
+                else if (v < e_unbind) ev = EV_UNBIND;
+                else if (v < e_exit) ev = EV_EXIT;
+                else ev = EV_FLIP;
+                int cap = M.K - occ_t;                       // free capacity of the hop target at step start
+                cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
+                code = (uint8_t)(ev | ((cap - 1) << 3));
+            }
+        }
+        const int r = (int)(slot / a.SH);
+        a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
+        STAMP(t_epi)
     }
-    const int r = (int)(slot / a.SH);
-    a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
+#ifdef APS_STAMPS
+    if (threadIdx.x == 0 && a.stamps) {
+        unsigned long long *o = a.stamps + (size_t)blockIdx.x * 8;
+        o[0] = t_fetch; o[1] = t_acc; o[2] = t_epi; o[3] = t_items; o[4] = __builtin_amdgcn_s_memtime() - t_start;
+        o[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
 struct CommitArgs {
     Model m;
     uint32_t *src; const uint32_t *orig; const uint8_t *prop;
-    uint32_t *pcnt, *plist; int2 *bounds; long long *gsum;
+    uint2 *spair; int4 *tinfo;
+    uint32_t *pcnt, *plist; long long *gsum;
     double *exit_log; unsigned *n_exit; int exit_cap;
+    unsigned *work_ctr;
     int Npad, SH, E, ntiles;
     double step_as_double;
 };
@@ -368,7 +503,10 @@ __device__ inline int hop_target(const Model &M, int p, int ev) {
 __global__ __launch_bounds__(256) void claim(const CommitArgs a) {
     const int e = blockIdx.y;
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot == 0) { a.gsum[2 * e] = 0; a.gsum[2 * e + 1] = 0; }      // apply() re-accumulates them
+    if (slot == 0) {
+        a.gsum[2 * e] = 0; a.gsum[2 * e + 1] = 0;            // apply() re-accumulates them
+        if (e == 0) *a.work_ctr = 0u;                         // next pair_propose launch starts at item 0
+    }
     if (slot >= (size_t)a.Npad) return;
     const int r = (int)(slot / a.SH);
     const uint8_t code = a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)];
@@ -411,8 +549,10 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
         }
         if (ev != EV_NONE) a.src[(size_t)e * a.Npad + slot] = me;
     }
-    // per-tile (= per-wave) bounds of the live sites, and the global spin sums
+    // pre-decoded source pair for the next all-pairs pass, per-tile (= per-wave) info, global spin sums
     const bool live = !(me & DEAD_BIT);
+    if (ev != EV_NONE)
+        a.spair[(size_t)e * a.Npad + slot] = make_uint2(live ? (uint32_t)p << 3 : DEAD_P8, (me & SPIN_BIT) ? SG_PLUS : SG_MINUS);
     int lo = live ? p : 0x7fffffff, hi = live ? p : -1;
     int ssum = live ? ((me & SPIN_BIT) ? 1 : -1) : 0, cnt = live ? 1 : 0;
 #pragma unroll
@@ -421,7 +561,7 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
         ssum += __shfl_xor(ssum, off); cnt += __shfl_xor(cnt, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        a.bounds[(size_t)e * a.ntiles + slot / TILE] = make_int2(lo, hi);
+        a.tinfo[(size_t)e * a.ntiles + slot / TILE] = make_int4(lo, hi, cnt < TILE ? 1 : 0, cnt);
         if (a.m.field_mode == 0 && cnt) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e]), (unsigned long long)(long long)ssum);
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e + 1]), (unsigned long long)cnt);
@@ -429,49 +569,44 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     }
 }
 
-// m-field on lattice sites: the same tile loop with the targets being sites instead of particles.
+// m-field on lattice sites: the same accumulation with the targets being sites instead of particles.
 struct FieldArgs {
     Model m; const long long *gsum;
     double *m_out; int tlen, ntiles, e;
 };
 
 template <int BC, bool TAB_LDS>
-__global__ __launch_bounds__(TILE *WAVES) void field_sites(const FieldArgs a, const uint32_t *__restrict__ src,
-                                                          const int2 *__restrict__ bounds,
-                                                          const double *__restrict__ table_g) {
+__global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const uint2 *__restrict__ spair,
+                                                       const int4 *__restrict__ tinfo,
+                                                       const double *__restrict__ table_g) {
     extern __shared__ double lds[];
     const Model &M = a.m;
     const int lane = threadIdx.x & (TILE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double *tab = table_g;
-    double *part = lds;
+    const size_t tdoubles = lds_table_doubles(a.tlen, TAB_LDS);
+    double *part = lds + tdoubles;
+    uint32_t *list = reinterpret_cast<uint32_t *>(part + (size_t)(WAVES - 1) * TILE * 4);
+    uint32_t *ctl = list + LIST_CAP;
+    uint32_t tbase = 0;
     if (TAB_LDS) {
-        for (int i = threadIdx.x; i <= a.tlen; i += TILE * WAVES) lds[i] = table_g[i];
-        tab = lds; part = lds + (a.tlen + 1);
+        for (int i = threadIdx.x; i <= a.tlen; i += NTHREADS) lds[i] = table_g[i];
+        typedef __attribute__((address_space(3))) double lds_double;
+        tbase = (uint32_t)(size_t)(lds_double *)lds;
     }
-    __syncthreads();
     const int x = blockIdx.x * TILE + lane;
     const int tlo = blockIdx.x * TILE, thi = min(tlo + TILE - 1, M.L - 1);
     const uint32_t pi8 = (uint32_t)min(x, M.L - 1) << 3;
-    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)M.L << 3;
-    const int R = a.tlen > 1 ? a.tlen - 1 : 1;
     double accW = 0.0, accS = 0.0;
     int c0 = 0, cl = 0, cr = 0;
-    for (int jt = wave; jt < a.ntiles; jt += WAVES) {
-        const int2 sb = bounds[jt];
-        if (sb.x > sb.y) continue;
-        bool direct, mirror;
-        tile_tests<BC>(tlo, thi, sb.x, sb.y, R, M.L, direct, mirror);
-        if (!(direct || mirror)) continue;
-        const uint32_t *__restrict__ tile = src + (size_t)jt * TILE;
-        if (BC == 0 && mirror) tile_loop<BC, true>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
-        else tile_loop<BC, false>(tile, pi8, tab, tlen8, L8, accW, accS, c0, cl, cr);
+    accumulate_targets<BC, TAB_LDS>(spair, tinfo, a.ntiles, tlo, thi, true, pi8, tbase, table_g, a.tlen, M.L, list, ctl, wave,
+                                    accW, accS, c0, cl, cr);
+    if (wave != 0) {
+        double *mine = part + ((size_t)(wave - 1) * TILE + lane) * 4;
+        mine[0] = accW; mine[1] = accS;
     }
-    double *mine = part + ((size_t)wave * TILE + lane) * 2;
-    mine[0] = accW; mine[1] = accS;
     __syncthreads();
     if (wave != 0 || x >= M.L) return;
-    for (int w = 1; w < WAVES; ++w) { accW += part[((size_t)w * TILE + lane) * 2]; accS += part[((size_t)w * TILE + lane) * 2 + 1]; }
+    for (int w = 0; w < WAVES - 1; ++w) { accW += part[((size_t)w * TILE + lane) * 4]; accS += part[((size_t)w * TILE + lane) * 4 + 1]; }
     if (M.field_mode == 0) { accS = (double)a.gsum[2 * a.e]; accW = (double)a.gsum[2 * a.e + 1]; }
     double mloc = 0.0;
     if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
@@ -497,13 +632,18 @@ struct aps_handle {
     bool own_stream = false;
     uint32_t *d_src = nullptr, *d_orig = nullptr, *d_pcnt = nullptr, *d_plist = nullptr;
     uint8_t *d_prop = nullptr, *d_prop_own = nullptr, *d_anchor = nullptr;
-    int2 *d_bounds = nullptr;
+    uint2 *d_spair = nullptr;
+    int4 *d_tinfo = nullptr;
+    unsigned *d_work_ctr = nullptr;
+    unsigned long long *d_stamps = nullptr;
+    bool ctr_dirty = true;
+    int num_cu = 256, wgs_per_cu = 1;
     double *d_table = nullptr, *d_beta = nullptr, *d_exit = nullptr, *d_S = nullptr, *d_W = nullptr, *d_mfield = nullptr;
     int *d_occ4 = nullptr;
     long long *d_gsum = nullptr;
     unsigned *d_nexit = nullptr;
     unsigned long long *d_tiles = nullptr;
-    uint32_t *d_tmp_src = nullptr; int2 *d_tmp_bounds = nullptr; size_t tmp_cap = 0;
+    uint2 *d_tmp_spair = nullptr; int4 *d_tmp_tinfo = nullptr; size_t tmp_cap = 0;
     int exit_cap = 0;
     int64_t step = 0;
     std::vector<int64_t> n_set;    // particles uploaded per ensemble
@@ -580,10 +720,27 @@ int dev_alloc(aps_handle *h, T **ptr, size_t count) {
     return APS_OK;
 }
 
-// host-side packing of one ensemble into slot order; fills bounds and the global sums
+// per-tile info and pre-decoded source pairs of a slot array (host mirror of what apply() maintains)
+void derive_sources(const std::vector<uint32_t> &src, std::vector<uint2> &spair, std::vector<int4> &tinfo) {
+    const size_t n = src.size(), nt = n / TILE;
+    spair.resize(n);
+    tinfo.assign(nt, make_int4(0x7fffffff, -1, 1, 0));
+    for (size_t s = 0; s < n; ++s) {
+        const uint32_t w = src[s];
+        const bool live = !(w & DEAD_BIT);
+        spair[s] = make_uint2(live ? (w & POS_MASK) << 3 : DEAD_P8, (w & SPIN_BIT) ? SG_PLUS : SG_MINUS);
+        if (!live) continue;
+        int4 &t = tinfo[s / TILE];
+        const int p = (int)(w & POS_MASK);
+        t.x = std::min(t.x, p); t.y = std::max(t.y, p); t.w += 1;
+    }
+    for (int4 &t : tinfo) t.z = t.w < TILE ? 1 : 0;
+}
+
+// host-side packing of one ensemble into slot order; fills the global sums
 void pack_ensemble(const aps_handle *h, const int32_t *pos, const int8_t *sigma, const uint8_t *bound,
                    const uint8_t *alive, int64_t n, std::vector<uint32_t> &src, std::vector<uint32_t> &orig,
-                   std::vector<int2> &bounds, long long gsum[2]) {
+                   long long gsum[2]) {
     const int64_t Npad = h->Npad;
     std::vector<uint32_t> order((size_t)n);
     std::iota(order.begin(), order.end(), 0u);
@@ -607,19 +764,23 @@ void pack_ensemble(const aps_handle *h, const int32_t *pos, const int8_t *sigma,
         src[(size_t)s] = w;
         orig[(size_t)s] = i;
     }
-    bounds.assign((size_t)h->ntiles, make_int2(0x7fffffff, -1));
-    for (int64_t s = 0; s < Npad; ++s) {
-        if (src[(size_t)s] & DEAD_BIT) continue;
-        int2 &b = bounds[(size_t)(s / TILE)];
-        const int p = (int)(src[(size_t)s] & POS_MASK);
-        b.x = std::min(b.x, p); b.y = std::max(b.y, p);
-    }
+}
+
+int upload_ensemble(aps_handle *h, int e, const std::vector<uint32_t> &src, const std::vector<uint32_t> &orig) {
+    std::vector<uint2> spair; std::vector<int4> tinfo;
+    derive_sources(src, spair, tinfo);
+    HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_spair + (size_t)e * h->Npad, spair.data(), spair.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tinfo + (size_t)e * h->ntiles, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
 }
 
 PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
     PairArgs a{};
     a.m = h->model;
-    a.orig = h->d_orig; a.gsum = h->d_gsum;
+    a.src = h->d_src; a.orig = h->d_orig; a.gsum = h->d_gsum; a.work_ctr = h->d_work_ctr; a.stamps = h->d_stamps;
     a.beta = h->d_beta; a.anchor = h->d_anchor; a.prop = h->d_prop; a.pcnt = h->d_pcnt;
     a.S_out = hook ? h->d_S : nullptr; a.W_out = hook ? h->d_W : nullptr; a.occ4_out = hook ? h->d_occ4 : nullptr;
     a.tiles_done = h->d_tiles;
@@ -633,10 +794,12 @@ PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
 int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) {
     PairArgs b = a;
     b.tile_lo = first_tile; b.tile_cnt = tile_cnt;
-    const dim3 grid((unsigned)tile_cnt, (unsigned)h->E), block(TILE * WAVES);
-    const size_t part = (size_t)WAVES * TILE * 4 * sizeof(double);
-    const size_t lds = h->table_in_lds ? (size_t)(h->tlen + 1) * sizeof(double) + part : part;
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_propose<BC, TL>), grid, block, lds, h->stream, b, h->d_src, h->d_bounds, h->d_table)
+    if (h->ctr_dirty) HIP_TRY(h, hipMemsetAsync(h->d_work_ctr, 0, sizeof(unsigned), h->stream));
+    h->ctr_dirty = true;                                    // apply() resets the counter; until then it is spent
+    const unsigned items = (unsigned)tile_cnt * (unsigned)h->E;
+    const dim3 grid(std::max(1u, std::min(items, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
+    const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_propose<BC, TL>), grid, block, lds, h->stream, b, h->d_spair, h->d_tinfo, h->d_table)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
@@ -647,34 +810,38 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
 CommitArgs commit_args(aps_handle *h) {
     CommitArgs c{};
     c.m = h->model; c.src = h->d_src; c.orig = h->d_orig; c.prop = h->d_prop; c.pcnt = h->d_pcnt;
-    c.plist = h->d_plist; c.bounds = h->d_bounds; c.gsum = h->d_gsum; c.exit_log = h->d_exit;
+    c.spair = h->d_spair; c.tinfo = h->d_tinfo; c.work_ctr = h->d_work_ctr;
+    c.plist = h->d_plist; c.gsum = h->d_gsum; c.exit_log = h->d_exit;
     c.n_exit = h->d_nexit; c.exit_cap = h->exit_cap; c.Npad = (int)h->Npad; c.SH = (int)h->SH; c.E = h->E;
     c.ntiles = (int)h->ntiles; c.step_as_double = (double)h->step;
     return c;
 }
 
 int set_lds_limit(aps_handle *h) {
-    const size_t part = (size_t)WAVES * TILE * 4 * sizeof(double);
-    const size_t need = (size_t)(h->tlen + 1) * sizeof(double) + part;
-    h->table_in_lds = need <= 150 * 1024;
-    if (h->table_in_lds && need > 48 * 1024) {
+    h->table_in_lds = lds_total_bytes(h->tlen, true) <= 150 * 1024;
+    const size_t need = lds_total_bytes(h->tlen, h->table_in_lds);
+    if (need > 48 * 1024) {
         const int n = (int)need;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_propose<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_propose<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
     }
+    hipDeviceProp_t prop;
+    HIP_TRY(h, hipGetDeviceProperties(&prop, h->p.device));
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int by_lds = (int)((160 * 1024) / need), by_waves = 32 / WAVES;
+    h->wgs_per_cu = std::max(1, std::min(by_lds, by_waves));
     return APS_OK;
 }
 
-int launch_field(aps_handle *h, int e, const uint32_t *src, const int2 *bounds, int ntiles, double *m_out) {
+int launch_field(aps_handle *h, int e, const uint2 *spair, const int4 *tinfo, int ntiles, double *m_out) {
     FieldArgs f{};
     f.m = h->model; f.gsum = h->d_gsum; f.m_out = m_out;
     f.tlen = h->tlen; f.ntiles = ntiles; f.e = e;
-    const dim3 grid((unsigned)((h->p.L + TILE - 1) / TILE)), block(TILE * WAVES);
-    const size_t part = (size_t)WAVES * TILE * 2 * sizeof(double);
-    const size_t lds = h->table_in_lds ? (size_t)(h->tlen + 1) * sizeof(double) + part : part;
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, src, bounds, h->d_table)
+    const dim3 grid((unsigned)((h->p.L + TILE - 1) / TILE)), block(NTHREADS);
+    const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, spair, tinfo, h->d_table)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
@@ -693,6 +860,7 @@ int do_commit(aps_handle *h) {
     hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);
     hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
     HIP_TRY(h, hipGetLastError());
+    h->ctr_dirty = false;                                   // claim() reset the work counter
     h->step += 1;
     return APS_OK;
 }
@@ -759,7 +927,8 @@ int aps_create(const aps_params *p, aps_handle **out) {
     const size_t EN = (size_t)h->E * (size_t)h->Npad, EL = (size_t)h->E * (size_t)p->L;
     h->exit_cap = (int)std::max<int64_t>(h->N, 1);
     if ((rc = dev_alloc(h, &h->d_src, EN)) || (rc = dev_alloc(h, &h->d_orig, EN)) || (rc = dev_alloc(h, &h->d_prop_own, EN)) ||
-        (rc = dev_alloc(h, &h->d_bounds, (size_t)h->E * h->ntiles)) || (rc = dev_alloc(h, &h->d_pcnt, EL)) ||
+        (rc = dev_alloc(h, &h->d_spair, EN)) || (rc = dev_alloc(h, &h->d_tinfo, (size_t)h->E * h->ntiles)) ||
+        (rc = dev_alloc(h, &h->d_work_ctr, 1)) || (rc = dev_alloc(h, &h->d_stamps, (size_t)8 * 4096)) || (rc = dev_alloc(h, &h->d_pcnt, EL)) ||
         (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size())) ||
         (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)2 * h->E)) ||
         (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
@@ -782,9 +951,9 @@ void aps_destroy(aps_handle *h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
-    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_bounds, h->d_table, h->d_beta,
-                    h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum, h->d_nexit, h->d_tiles, h->d_tmp_src,
-                    h->d_tmp_bounds};
+    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_spair, h->d_tinfo,
+                    h->d_work_ctr, h->d_stamps, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
+                    h->d_nexit, h->d_tiles, h->d_tmp_spair, h->d_tmp_tinfo};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -809,11 +978,10 @@ int aps_set_state(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *si
         if (sigma[i] != 1 && sigma[i] != -1) return fail(h, APS_ERR_ARG, "aps_set_state: sigma must be +1 or -1");
         if (!(alive && !alive[i]) && ++occ[(size_t)pos[i]] > h->p.K) return fail(h, APS_ERR_ARG, "aps_set_state: site capacity exceeded");
     }
-    std::vector<uint32_t> src, orig; std::vector<int2> bounds; long long gsum[2];
-    pack_ensemble(h, pos, sigma, bound, alive, n, src, orig, bounds, gsum);
-    HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_bounds + (size_t)e * h->ntiles, bounds.data(), bounds.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    std::vector<uint32_t> src, orig; long long gsum[2];
+    pack_ensemble(h, pos, sigma, bound, alive, n, src, orig, gsum);
+    int rc = upload_ensemble(h, e, src, orig);
+    if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gsum, sizeof(gsum), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_nexit + e, 0, sizeof(unsigned), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -947,6 +1115,14 @@ int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes) {
     return APS_OK;
 }
 
+// diagnostic builds only (-DAPS_STAMPS): per-workgroup phase cycle totals of the last pair_propose launch
+int aps_debug_stamps(aps_handle *h, unsigned long long *out, int64_t nwords) {
+    if (!h || !out) return APS_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->d_stamps, (size_t)std::min<int64_t>(nwords, 8 * 4096) * 8, hipMemcpyDeviceToHost));
+    return APS_OK;
+}
+
 int aps_time(aps_handle *h, double *t, int64_t *step_index) {
     if (!h) return APS_ERR_ARG;
     if (t) *t = (double)h->step * h->p.dt;
@@ -1000,12 +1176,9 @@ int aps_resort(aps_handle *h) {
         std::vector<int32_t> pos((size_t)n); std::vector<int8_t> sg((size_t)n); std::vector<uint8_t> bd((size_t)n), al((size_t)n);
         int rc = aps_get_state(h, e, pos.data(), sg.data(), bd.data(), al.data(), n);
         if (rc) return rc;
-        std::vector<uint32_t> src, orig; std::vector<int2> bounds; long long gsum[2];
-        pack_ensemble(h, pos.data(), sg.data(), bd.data(), al.data(), n, src, orig, bounds, gsum);
-        HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_bounds + (size_t)e * h->ntiles, bounds.data(), bounds.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::vector<uint32_t> src, orig; long long gsum[2];
+        pack_ensemble(h, pos.data(), sg.data(), bd.data(), al.data(), n, src, orig, gsum);
+        if ((rc = upload_ensemble(h, e, src, orig))) return rc;
     }
     return APS_OK;
 }
@@ -1028,7 +1201,7 @@ int aps_observe(aps_handle *h, int32_t e, int64_t *counts_p, int64_t *counts_m, 
         }
     }
     if (m_field) {
-        int rc = launch_field(h, e, h->d_src + (size_t)e * h->Npad, h->d_bounds + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
+        int rc = launch_field(h, e, h->d_spair + (size_t)e * h->Npad, h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
         if (rc) return rc;
         HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1051,25 +1224,21 @@ int aps_field_from_counts(aps_handle *h, int32_t e, const int64_t *counts_p, con
     if (gs[1] > (long long)4 * h->p.K * L) return fail(h, APS_ERR_ARG, "aps_field_from_counts: more than 4*K*L particles would break the exact-sum bound");
     const size_t nt = (src.size() + TILE - 1) / TILE + 1;
     src.resize(nt * TILE, DEAD_BIT);
-    std::vector<int2> bounds(nt, make_int2(0x7fffffff, -1));
-    for (size_t s = 0; s < src.size(); ++s) {
-        if (src[s] & DEAD_BIT) continue;
-        const int p = (int)(src[s] & POS_MASK);
-        bounds[s / TILE].x = std::min(bounds[s / TILE].x, p); bounds[s / TILE].y = std::max(bounds[s / TILE].y, p);
-    }
+    std::vector<uint2> spair; std::vector<int4> tinfo;
+    derive_sources(src, spair, tinfo);
     if (nt > h->tmp_cap) {
-        if (h->d_tmp_src) { (void)hipFree(h->d_tmp_src); (void)hipFree(h->d_tmp_bounds); h->d_tmp_src = nullptr; h->d_tmp_bounds = nullptr; }
+        if (h->d_tmp_spair) { (void)hipFree(h->d_tmp_spair); (void)hipFree(h->d_tmp_tinfo); h->d_tmp_spair = nullptr; h->d_tmp_tinfo = nullptr; }
         int rc;
-        if ((rc = dev_alloc(h, &h->d_tmp_src, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_bounds, nt))) return rc;
+        if ((rc = dev_alloc(h, &h->d_tmp_spair, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_tinfo, nt))) return rc;
         h->tmp_cap = nt;
     }
     long long saved[2];
     HIP_TRY(h, hipMemcpyAsync(saved, h->d_gsum + 2 * e, sizeof(saved), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_src, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_bounds, bounds.data(), bounds.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_spair, spair.data(), spair.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_tinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gs, sizeof(gs), hipMemcpyHostToDevice, h->stream));
-    int rc = launch_field(h, e, h->d_tmp_src, h->d_tmp_bounds, (int)nt, h->d_mfield);
+    int rc = launch_field(h, e, h->d_tmp_spair, h->d_tmp_tinfo, (int)nt, h->d_mfield);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, saved, sizeof(saved), hipMemcpyHostToDevice, h->stream));
