@@ -6,8 +6,10 @@ the exported symbols against the header)."""
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
 import re
+import sys
 
 import numpy as np
 
@@ -48,11 +50,27 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(aps_[a-z_0-9]+)\s*\(", text)))
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, the name libaps_hip.so links against).  If our library pulled in the system copy first,
+    a later `import torch` would start a SECOND runtime and find no GPUs.  Loading torch's copy first makes the
+    dynamic linker resolve our NEEDED entry to it, whatever the import order (torch.distributed is the
+    multi-GPU plumbing).  APS_SYSTEM_HIP_RUNTIME=1 opts out (never combine that with torch)."""
+    if "torch" in sys.modules or os.environ.get("APS_SYSTEM_HIP_RUNTIME") == "1":
+        return None
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    return C.CDLL(cand, mode=C.RTLD_GLOBAL) if os.path.exists(cand) else None
+
+
 def load():
     """dlopen the library (no GPU needed for this) and declare the prototypes."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python {os.path.join(HERE, 'build.py')}` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

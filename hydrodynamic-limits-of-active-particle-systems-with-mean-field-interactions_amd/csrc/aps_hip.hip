@@ -963,8 +963,7 @@ int aps_set_stream(aps_handle *h, void *hip_stream) {
     if (!h) return APS_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) { HIP_TRY(h, hipStreamDestroy(h->stream)); h->own_stream = false; }
-    if (hip_stream) h->stream = reinterpret_cast<hipStream_t>(hip_stream);
-    else { HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);   // taken literally: NULL is the legacy default stream
     return APS_OK;
 }
 

@@ -60,7 +60,9 @@ const char *aps_last_error(const aps_handle *h);   /* h may be NULL: error of th
 int aps_create(const aps_params *p, aps_handle **out);
 void aps_destroy(aps_handle *h);
 
-/* Run subsequent launches on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
+/* Run all subsequent launches and copies on a caller-owned hipStream_t, taken literally: NULL means the
+ * legacy default stream (which is what torch.cuda.current_stream() is unless a side stream is active).
+ * Until this is called the handle uses a private non-blocking stream. */
 int aps_set_stream(aps_handle *h, void *hip_stream);
 
 /* State exchange in ORIGINAL particle order (the order init_particles returned, ref :191-195).

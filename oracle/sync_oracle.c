@@ -323,32 +323,26 @@ void orc_rates(const orc_params *P, const uint8_t *anchor, int64_t n, const int3
  * proposal codes */
 enum { EV_NONE = 0, EV_LEFT = 1, EV_RIGHT = 2, EV_FWD = 3, EV_BIND = 4, EV_UNBIND = 5, EV_EXIT = 6, EV_FLIP = 7 };
 
-/* Advances the state by one dt.  Index i is the particle's original index (Philox counter word 2).
- * Optional outputs (may be NULL): prop[n] proposal code per particle, accepted[n] 1 if the proposal
- * was carried out, Sout/Wout[n], occ4[4n].
- * Exits are appended as (time, position, index) triples to exit_log (capacity exit_cap triples);
- * *n_exit is advanced.  Returns 0, or -1 if exit_log overflowed. */
-int32_t orc_sync_step(const orc_params *P, const double *wtab, const uint8_t *anchor, int64_t n, int32_t *pos,
-                      int8_t *spin, uint8_t *bound, uint8_t *alive, uint64_t step, uint8_t *prop_out,
-                      uint8_t *accepted_out, double *Sout, double *Wout, double *exit_log, int64_t exit_cap,
-                      int64_t *n_exit) {
+/* Phase 1 of a step for the particles lo <= i < hi only (what one rank of a sharded job evaluates):
+ * proposal byte = event code | (free capacity of the hop target - 1) << 3, the format the ranks exchange.
+ * S/W are optional outputs for [lo, hi). */
+void orc_sync_propose(const orc_params *P, const double *wtab, const uint8_t *anchor, int64_t n, const int32_t *pos,
+                      const int8_t *spin, const uint8_t *bound, const uint8_t *alive, uint64_t step, int64_t lo,
+                      int64_t hi, uint8_t *prop, double *Sout, double *Wout) {
     const int32_t L = P->L, K = P->K;
     int32_t *cp = (int32_t *)malloc(sizeof(int32_t) * (size_t)L), *cm = (int32_t *)malloc(sizeof(int32_t) * (size_t)L);
     int32_t *occ = (int32_t *)malloc(sizeof(int32_t) * (size_t)L);
-    int32_t *taken = (int32_t *)calloc((size_t)L, sizeof(int32_t));
-    double *S = (double *)malloc(sizeof(double) * (size_t)n), *W = (double *)malloc(sizeof(double) * (size_t)n);
-    uint8_t *prop = (uint8_t *)malloc((size_t)n);
-    int32_t *target = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    const int64_t m = hi - lo;
+    double *S = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1)), *W = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
     histogram(L, n, pos, spin, alive, cp, cm);
     for (int32_t x = 0; x < L; ++x) occ[x] = cp[x] + cm[x];
-    field_at(P, wtab, cp, cm, pos, n, S, W);
+    field_at(P, wtab, cp, cm, pos + lo, m, S, W);
     const uint32_t key[2] = {(uint32_t)P->seed, (uint32_t)(P->seed >> 32)};
-    /* phase 1: every particle draws its proposal from the state at the start of the step */
-    for (int64_t i = 0; i < n; ++i) {
-        prop[i] = EV_NONE; target[i] = -1;
+    for (int64_t i = lo; i < hi; ++i) {
+        prop[i] = EV_NONE;
         if (!alive[i]) continue;
         chan_t c;
-        channels(P, anchor, pos[i], spin[i], bound[i], clip_ratio(S[i], W[i]), occ, &c, orc_exp);
+        channels(P, anchor, pos[i], spin[i], bound[i], clip_ratio(S[i - lo], W[i - lo]), occ, &c, orc_exp);
         const double r = c.ch[CH_TOTAL];
         const uint32_t ctr[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)i, P->ensemble};
         uint32_t x[4];
@@ -360,27 +354,44 @@ int32_t orc_sync_step(const orc_params *P, const double *wtab, const uint8_t *an
         const double v = u1 * r;                                        /* ref :362 */
         const double e_diff = c.ch[CH_DIFF], e_act = e_diff + c.ch[CH_ACT], e_bind = e_act + c.ch[CH_BIND],
                      e_unbind = e_bind + c.ch[CH_UNBIND], e_exit = e_unbind + c.ch[CH_EXIT];   /* ref :363-367 */
+        int ev = EV_NONE, target = -1;
         if (v < e_diff) {
             const double a = c.ch[CH_LEFT], b = c.ch[CH_RIGHT];
             if (a + b <= 0.0) continue;
-            if (u2 < a / (a + b)) { prop[i] = EV_LEFT; target[i] = c.left; }        /* ref :378-381 */
-            else { prop[i] = EV_RIGHT; target[i] = c.right; }
-        } else if (v < e_act) { prop[i] = EV_FWD; target[i] = c.fwd; }
-        else if (v < e_bind) prop[i] = EV_BIND;
-        else if (v < e_unbind) prop[i] = EV_UNBIND;
-        else if (v < e_exit) prop[i] = EV_EXIT;
-        else prop[i] = EV_FLIP;
+            if (u2 < a / (a + b)) { ev = EV_LEFT; target = c.left; }    /* ref :378-381 */
+            else { ev = EV_RIGHT; target = c.right; }
+        } else if (v < e_act) { ev = EV_FWD; target = c.fwd; }
+        else if (v < e_bind) ev = EV_BIND;
+        else if (v < e_unbind) ev = EV_UNBIND;
+        else if (v < e_exit) ev = EV_EXIT;
+        else ev = EV_FLIP;
+        int cap = target >= 0 ? K - occ[target] : 1;
+        cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
+        prop[i] = (uint8_t)(ev | ((cap - 1) << 3));
     }
-    /* phase 2: commit.  Hops into a site are granted in increasing particle index while
-     * occupancy-at-start + granted < K; everything else always succeeds. */
+    if (Sout) memcpy(Sout, S, sizeof(double) * (size_t)m);
+    if (Wout) memcpy(Wout, W, sizeof(double) * (size_t)m);
+    free(cp); free(cm); free(occ); free(S); free(W);
+}
+
+/* Phase 2: apply ALL n proposals.  Hops into a site are granted in increasing particle index while fewer
+ * than `cap` (the free capacity at step start, carried in the proposal byte) have been granted; everything
+ * else always succeeds.  A pure function of (state, proposals): every rank computes the same result. */
+int32_t orc_sync_commit(const orc_params *P, int64_t n, int32_t *pos, int8_t *spin, uint8_t *bound, uint8_t *alive,
+                        uint64_t step, const uint8_t *prop, uint8_t *accepted_out, double *exit_log, int64_t exit_cap,
+                        int64_t *n_exit) {
+    const int32_t L = P->L;
+    int32_t *taken = (int32_t *)calloc((size_t)L, sizeof(int32_t));
     int32_t rc = 0;
     const double t_now = (double)step * P->dt;
     for (int64_t i = 0; i < n; ++i) {
         int ok = 0;
-        switch (prop[i]) {
+        const int ev = prop[i] & 7, cap = (prop[i] >> 3) + 1;
+        if (alive[i]) switch (ev) {
             case EV_LEFT: case EV_RIGHT: case EV_FWD: {
-                const int32_t s = target[i];
-                if (occ[s] + taken[s] < K) { taken[s]++; pos[i] = s; ok = 1; }
+                int32_t s = ev == EV_LEFT ? pos[i] - 1 : pos[i] + 1;
+                if (P->periodic) s = s < 0 ? s + L : (s >= L ? s - L : s);
+                if (taken[s] < cap) { taken[s]++; pos[i] = s; ok = 1; }
                 break;
             }
             case EV_BIND: bound[i] = 1; ok = 1; break;
@@ -397,10 +408,22 @@ int32_t orc_sync_step(const orc_params *P, const double *wtab, const uint8_t *an
         }
         if (accepted_out) accepted_out[i] = (uint8_t)ok;
     }
-    if (prop_out) memcpy(prop_out, prop, (size_t)n);
-    if (Sout) memcpy(Sout, S, sizeof(double) * (size_t)n);
-    if (Wout) memcpy(Wout, W, sizeof(double) * (size_t)n);
-    free(cp); free(cm); free(occ); free(taken); free(S); free(W); free(prop); free(target);
+    free(taken);
+    return rc;
+}
+
+/* One synchronous step = propose for everybody + commit.  Index i is the particle's original index (Philox
+ * counter word 2).  Optional outputs (may be NULL): prop[n], accepted[n], Sout/Wout[n].  Exits are appended
+ * as (time, position, index) triples to exit_log; returns 0, or -1 if exit_log overflowed. */
+int32_t orc_sync_step(const orc_params *P, const double *wtab, const uint8_t *anchor, int64_t n, int32_t *pos,
+                      int8_t *spin, uint8_t *bound, uint8_t *alive, uint64_t step, uint8_t *prop_out,
+                      uint8_t *accepted_out, double *Sout, double *Wout, double *exit_log, int64_t exit_cap,
+                      int64_t *n_exit) {
+    uint8_t *prop = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    orc_sync_propose(P, wtab, anchor, n, pos, spin, bound, alive, step, 0, n, prop, Sout, Wout);
+    const int32_t rc = orc_sync_commit(P, n, pos, spin, bound, alive, step, prop, accepted_out, exit_log, exit_cap, n_exit);
+    if (prop_out) for (int64_t i = 0; i < n; ++i) prop_out[i] = prop[i] & 7;
+    free(prop);
     return rc;
 }
 

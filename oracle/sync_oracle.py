@@ -32,6 +32,7 @@ def lib():
         _lib.orc_exp.argtypes = [C.c_double]
         _lib.orc_build_table.restype = C.c_int32
         _lib.orc_sync_step.restype = C.c_int32
+        _lib.orc_sync_commit.restype = C.c_int32
         _lib.orc_sync_run.restype = C.c_int32
     return _lib
 
@@ -144,6 +145,19 @@ class SyncOracle:
         self.step_index += 1
         if want_detail:
             return dict(prop=prop, accepted=acc, S=S, W=W)
+
+    def propose(self, lo, hi, prop):
+        """Proposal bytes of particles lo..hi-1 into prop[lo:hi] (uint8 array of length n)."""
+        lib().orc_sync_propose(C.byref(self.c), _p(self.table), _p(self.anchor), C.c_int64(self.n), _p(self.pos),
+                               _p(self.spin), _p(self.bound), _p(self.alive), C.c_uint64(self.step_index),
+                               C.c_int64(lo), C.c_int64(hi), _p(prop), None, None)
+
+    def commit(self, prop):
+        rc = lib().orc_sync_commit(C.byref(self.c), C.c_int64(self.n), _p(self.pos), _p(self.spin), _p(self.bound),
+                                   _p(self.alive), C.c_uint64(self.step_index), _p(prop), None, _p(self._exit_buf),
+                                   C.c_int64(len(self._exit_buf)), C.byref(self._n_exit))
+        assert rc == 0
+        self.step_index += 1
 
     def run(self, nsteps):
         rc = lib().orc_sync_run(C.byref(self.c), _p(self.table), _p(self.anchor), C.c_int64(self.n),

@@ -275,3 +275,79 @@ def test_full_size_properties(capi):
     finally:
         a.close()
         b.close()
+
+
+def test_two_rank_shards_emulated_on_one_gpu(capi):
+    """world=2 on ONE device: each handle evaluates its own particle shard, the proposal blocks are swapped
+    by hand (what the all-gather does), both commit everything -> identical states, equal to world=1."""
+    torch = pytest.importorskip("torch")
+    par = params(L=2000, K=2, sigma=0.02, anchor_positions=[0.5], anchor_radius=0.05, k_on=2.0, k_off=1.0, k_exit=0.5)
+    rng = np.random.default_rng(21)
+    N = 1500
+    pos, spin = random_state(rng, par.L, N, par.K)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ranks = []
+    for r in range(2):
+        h = make_handle(capi, par, N, dt=0.04, seed=8, rank=r, world=2)
+        h.set_state(pos, spin)
+        _, total, off, mine = h.exchange_buffer()
+        buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        h.set_stream(stream)
+        h.bind_exchange_buffer(buf.data_ptr(), total)
+        ranks.append((h, buf, off, mine))
+    single = make_handle(capi, par, N, dt=0.04, seed=8)
+    try:
+        single.set_state(pos, spin)
+        assert ranks[0][2] == 0 and ranks[1][2] == ranks[0][3]
+        with pytest.raises(capi.ApsError):
+            ranks[0][0].step(1)                           # aps_step refuses sharded handles
+        for _ in range(60):
+            for h, _, _, _ in ranks:
+                h.propose()
+            (h0, b0, o0, m0), (h1, b1, o1, m1) = ranks
+            b0[o1:o1 + m1] = b1[o1:o1 + m1]
+            b1[o0:o0 + m0] = b0[o0:o0 + m0]
+            for h, _, _, _ in ranks:
+                h.commit()
+        torch.cuda.synchronize()
+        single.step(60)
+        want = single.get_state()
+        for h, _, _, _ in ranks:
+            for x, y in zip(h.get_state(), want):
+                assert np.array_equal(x, y)
+        assert np.array_equal(ranks[0][0].exits(), single.exits())
+    finally:
+        for h, _, _, _ in ranks:
+            h.close()
+        single.close()
+
+
+def test_hip_engine_over_nccl_world1(capi):
+    """The production multi-GPU path (ShardedStepper + HipEngine + torch.distributed 'nccl' = RCCL) at world
+    size 1: exercises the torch-tensor <-> C-ABI pointer hand-over, the shared stream and the collective call."""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    sharded = importlib.import_module(PKG + ".sharded")
+    par = params(L=1000, K=1, sigma=0.02)
+    rng = np.random.default_rng(4)
+    pos, spin = random_state(rng, 1000, 450, 1)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1)
+    a = make_handle(capi, par, 450, seed=12)
+    b = make_handle(capi, par, 450, seed=12)
+    try:
+        a.set_state(pos, spin)
+        b.set_state(pos, spin)
+        stepper = sharded.ShardedStepper(sharded.HipEngine(a, torch.device("cuda", 0)))
+        assert stepper.world == 1
+        stepper.step(50)
+        stepper.dist.all_gather_into_tensor(stepper.buf, stepper.mine)     # the collective itself, in place
+        torch.cuda.synchronize()
+        b.step(50)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert np.array_equal(x, y)
+    finally:
+        a.close()
+        b.close()
+        dist.destroy_process_group()

@@ -1,0 +1,102 @@
+"""GPU suite: the drop-in surface `from PARTICLE_solver_CLASS import ParticleSystem` -- result dictionary
+contract (reference :542-557) and bit-exact agreement of every snapshot with the oracle stepped by hand."""
+import numpy as np
+import pytest
+
+from oracle.gillespie_numpy import LatticeGasParams
+from oracle import sync_oracle as so
+from conftest import table_callable
+
+pytestmark = pytest.mark.gpu
+
+REF_KEYS = ["times_obs", "pos_list", "rho_p_list", "rho_m_list", "total_list", "particle_count_list", "bound_list",
+            "m_local_list", "m_global", "rho_hat_complex", "fft_amp_list", "var_list", "exit_times", "exit_positions"]
+
+
+def _oracle_replay(ps, pos0, sigma0, seed, T, obs_dt):
+    par = LatticeGasParams.from_kwargs(
+        L=ps.L, xlim=ps.xlim, rate_diffusion=ps.rate_diffusion, rate_active=ps.rate_active, beta=ps.beta,
+        scale_rates=False, local_kernel_sigma=ps.local_kernel_sigma, periodic=ps.periodic,
+        minus_anchor=ps.minus_anchor, immobilize_when_anchored=ps.immobilize_when_anchored,
+        anchor_positions=ps.anchor_positions, anchor_radius=ps.anchor_radius, site_capacity=ps.K,
+        crowding_suppresses_rates=ps.crowding_suppresses_rates, k_on=ps.k_on, k_off=ps.k_off,
+        suppress_flip_when_bound=ps.suppress_flip_when_bound, k_exit=ps.k_exit)
+    orc = so.SyncOracle(par, dt=ps.dt, seed=seed)
+    orc.set_state(pos0, sigma0)
+    snaps, done = [], 0
+    for t in np.arange(0.0, T, obs_dt):
+        want = int(np.ceil(t / ps.dt - 1e-9))
+        orc.run(want - done)
+        done = want
+        live = orc.alive.astype(bool)
+        snaps.append((orc.pos[live].astype(np.int64), orc.spin[live].copy(), orc.bound[live].astype(bool),
+                      orc.field_sites()[2]))
+    return snaps, orc.exits()
+
+
+@pytest.mark.parametrize("variant", ["fixed_reflect", "poisson_periodic_anchors"])
+def test_run_contract_and_oracle_replay(variant):
+    from PARTICLE_solver_CLASS import ParticleSystem
+    if variant == "fixed_reflect":
+        kw = dict(L=400, xlim=1.0, rate_diffusion=0.3, rate_active=4.0, beta=1.1, init="fixed", N=180,
+                  scale_rates=False, local_kernel_sigma=0.02, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0)
+    else:
+        L = 300
+        rp = 0.9 * np.exp(-np.arange(L) / L / 0.4)
+        rm = np.full(L, 0.35)
+        kw = dict(L=L, xlim=1.0, rate_diffusion=0.3, rate_active=3.0, beta=0.8, init="poisson",
+                  rho0_plus=table_callable(rp), rho0_minus=table_callable(rm), scale_rates=False,
+                  local_kernel_sigma=0.03, periodic=True, site_capacity=2, anchor_positions=[0.3, 0.6],
+                  anchor_radius=0.05, k_on=3.0, k_off=1.0, k_exit=1.5)
+    T, obs_dt = 3.0, 0.25
+    ps = ParticleSystem(rng=np.random.default_rng(5), dt=0.02, seed=777, **kw)
+    out = ps.run(T=T, obs_dt=obs_dt, record_fft=True, record_var=True)
+    # ---- contract: keys, order, types, shapes (reference :542-557)
+    assert list(out.keys()) == REF_KEYS
+    M, L = len(out["times_obs"]), ps.L
+    assert np.array_equal(out["times_obs"], np.arange(0.0, T, obs_dt))
+    assert isinstance(out["pos_list"], list) and len(out["pos_list"]) == M and out["pos_list"][0].dtype == np.int64
+    for k in ("rho_p_list", "rho_m_list", "total_list", "m_local_list"):
+        assert out[k].shape == (M, L) and out[k].dtype == np.float64
+    assert out["rho_hat_complex"].dtype == np.complex128 and out["fft_amp_list"].shape == (M, L)
+    assert out["var_list"].shape == (M,) and out["m_global"].shape == (M,)
+    assert all(isinstance(c, int) for c in out["particle_count_list"])
+    assert out["bound_list"][0].dtype == bool
+    np.testing.assert_allclose(out["total_list"].sum(axis=1) * ps.dx, 1.0, rtol=1e-12)     # reference :209-213
+    assert np.all(np.abs(out["m_local_list"]) <= 1.0)
+    assert np.array_equal(out["fft_amp_list"], np.abs(np.fft.fft(out["total_list"], axis=1)))
+    # ---- same initial condition as the reference's Generator calls, then oracle replay bit for bit
+    ps2 = ParticleSystem(rng=np.random.default_rng(5), **kw)
+    pos0, sigma0 = ps2.init_particles()
+    assert np.array_equal(out["pos_list"][0], pos0)
+    snaps, exits = _oracle_replay(ps, pos0, sigma0, 777, T, obs_dt)
+    for k, (p, s, b, m) in enumerate(snaps):
+        assert np.array_equal(out["pos_list"][k], p), k
+        assert np.array_equal(out["bound_list"][k], b), k
+        assert out["particle_count_list"][k] == len(p)
+        assert out["m_global"][k] == np.mean(s)
+        assert np.array_equal(out["m_local_list"][k], m), k
+    assert out["exit_times"] == [float(t) for t in exits[:, 0]]
+    assert out["exit_positions"] == [int(x) for x in exits[:, 1]]
+    if variant != "fixed_reflect":
+        assert len(out["exit_times"]) > 0 and out["particle_count_list"][-1] < out["particle_count_list"][0]
+
+
+def test_compute_local_m_field_method_matches_reference_fixture(golden):
+    """The public method (reference :216) on the GPU vs fixture G1, non-periodic cases (<= 2e-11)."""
+    from PARTICLE_solver_CLASS import ParticleSystem
+    g = golden("g1_mfield.npz")
+    base = g.meta["base_kw"]
+    n = 0
+    for idx, c in enumerate(g.meta["cases"]):
+        if c["periodic"]:
+            continue
+        ps = ParticleSystem(L=c["L"], N=c["N"], site_capacity=c["K"], local_kernel_sigma=c["sigma"],
+                            periodic=False, rng=np.random.default_rng(0), **base)
+        pos, sigma = g[f"c{idx}_pos"].astype(np.int64), g[f"c{idx}_sigma"]
+        cp = np.bincount(pos[sigma == 1], minlength=c["L"])
+        cm = np.bincount(pos[sigma == -1], minlength=c["L"])
+        m = ps.compute_local_m_field(cp, cm)
+        assert m.shape == (c["L"],) and np.max(np.abs(m - g[f"c{idx}_m"])) <= 2e-11, c
+        n += 1
+    assert n >= 20

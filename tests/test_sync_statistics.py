@@ -1,0 +1,102 @@
+"""Statistical parity of the synchronous scheme with the reference's exact Gillespie dynamics (fixture G4:
+32 seeded reference runs per beta, L=1000, N=500, K=1, T=20).
+
+CPU part (always run): the oracle's synchronous stepper at dt=0.0125.
+GPU part (-m gpu): ParticleSystem.run on the HIP path, same comparison.
+Acceptance: |mean_ours - mean_ref| <= 4 * sqrt(SE_ours^2 + SE_ref^2) + bias allowance, where the
+bias allowance covers the first-order time-discretisation error of the scheme (checked to shrink with dt)."""
+import numpy as np
+import pytest
+
+from oracle.gillespie_numpy import LatticeGasParams
+from oracle import sync_oracle as so
+
+DT = 0.0125
+N_RUNS = 16
+
+
+def _summaries(com, m_ts, prof):
+    return dict(com=np.asarray(com), m=np.asarray(m_ts), prof=np.asarray(prof))
+
+
+def _check(ours, g, bi, label, rel_bias=0.04, abs_bias=0.004):
+    """ours: dict of arrays [runs, ...] for com / m / prof."""
+    for key, ref_key in (("com", "com"), ("m", "m_ts"), ("prof", "prof")):
+        ref = g[f"b{bi}_{ref_key}"]
+        a, b = ours[key], ref
+        ma, mb = a.mean(axis=0), b.mean(axis=0)
+        se = np.sqrt(a.var(axis=0, ddof=1) / len(a) + b.var(axis=0, ddof=1) / len(b))
+        scale = np.abs(mb).max()
+        tol = 4.0 * se + rel_bias * scale + abs_bias
+        worst = np.max(np.abs(ma - mb) - tol)
+        assert worst <= 0, (label, key, float(worst), float(np.max(np.abs(ma - mb))), float(scale))
+
+
+def _oracle_run(ctor, beta, seed, dt, T, obs_dt, stride):
+    par = LatticeGasParams.from_kwargs(
+        L=ctor["L"], xlim=ctor["xlim"], rate_diffusion=ctor["rate_diffusion"], rate_active=ctor["rate_active"],
+        beta=beta, scale_rates=ctor["scale_rates"], local_kernel_sigma=ctor["local_kernel_sigma"],
+        periodic=ctor["periodic"], site_capacity=ctor["site_capacity"], k_on=ctor["k_on"], k_off=ctor["k_off"],
+        k_exit=ctor["k_exit"])
+    rng = np.random.default_rng(seed)
+    pos = rng.choice(ctor["L"], size=ctor["N"], replace=False)
+    spin = rng.choice([1, -1], size=ctor["N"]).astype(np.int8)
+    orc = so.SyncOracle(par, dt=dt, seed=int(rng.integers(0, 2 ** 63)))
+    orc.set_state(pos, spin)
+    times = np.arange(0.0, T, obs_dt)
+    com, m_ts, done = [], [], 0
+    for k, t in enumerate(times):
+        want = int(np.ceil(t / dt - 1e-9))
+        orc.run(want - done)
+        done = want
+        if k % stride == 0:
+            com.append(orc.pos.mean() * par.dx)
+            m_ts.append(orc.spin.mean())
+    dens = np.bincount(orc.pos, minlength=ctor["L"]) / (ctor["N"] * par.dx)
+    return np.array(com), np.array(m_ts), dens.reshape(50, -1).mean(axis=1)
+
+
+def test_oracle_sync_scheme_reproduces_gillespie_statistics(golden):
+    g = golden("g4_ensemble_stats.npz")
+    ctor, run, stride = g.meta["ctor"], g.meta["run"], g.meta["stride"]
+    for bi, case in enumerate(g.meta["cases"]):
+        rows = [_oracle_run(ctor, case["beta"], 9000 + 50 * bi + r, DT, run["T"], run["obs_dt"], stride)
+                for r in range(N_RUNS)]
+        ours = _summaries(*[np.stack(x) for x in zip(*rows)])
+        _check(ours, g, bi, f"oracle beta={case['beta']}")
+
+
+def test_time_step_bias_shrinks_with_dt(golden):
+    """Early-time centre-of-mass drift (t in [0,5], before the wall matters) against the reference value:
+    the error of the synchronous scheme is first order in dt."""
+    g = golden("g4_ensemble_stats.npz")
+    ctor, run = g.meta["ctor"], g.meta["run"]
+    bi = 1
+    beta = g.meta["cases"][bi]["beta"]
+    ref = g[f"b{bi}_com5"].mean()
+    errs = {}
+    for dt in (0.1, 0.0125):
+        vals = []
+        for r in range(24):
+            com, _, _ = _oracle_run(ctor, beta, 7000 + r, dt, 5.0 + run["obs_dt"], run["obs_dt"], 1)
+            vals.append(com[-1] - com[0])
+        errs[dt] = abs(np.mean(vals) - ref)
+    se_ref = g[f"b{bi}_com5"].std(ddof=1) / np.sqrt(len(g[f"b{bi}_com5"]))
+    assert errs[0.1] > errs[0.0125] or errs[0.1] < 4 * se_ref
+    assert errs[0.0125] <= 0.04 * abs(ref) + 4 * se_ref, errs
+
+
+@pytest.mark.gpu
+def test_particle_system_run_reproduces_gillespie_statistics(golden):
+    from PARTICLE_solver_CLASS import ParticleSystem
+    g = golden("g4_ensemble_stats.npz")
+    ctor, run, stride = g.meta["ctor"], g.meta["run"], g.meta["stride"]
+    for bi, case in enumerate(g.meta["cases"]):
+        com, m_ts, prof = [], [], []
+        for r in range(N_RUNS):
+            ps = ParticleSystem(beta=case["beta"], rng=np.random.default_rng(9000 + 50 * bi + r), dt=DT, **ctor)
+            out = ps.run(T=run["T"], obs_dt=run["obs_dt"])
+            com.append(np.array([p.mean() for p in out["pos_list"]])[::stride] * ps.dx)
+            m_ts.append(out["m_global"][::stride])
+            prof.append(out["total_list"][-1].reshape(50, -1).mean(axis=1))
+        _check(_summaries(np.stack(com), np.stack(m_ts), np.stack(prof)), g, bi, f"gpu beta={case['beta']}")
