@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -49,9 +50,11 @@ constexpr int TILE = 64;                      // slots per tile = one wavefront 
 constexpr int WAVES = APS_WAVES;              // waves per workgroup; they split the source tiles of one target tile
 constexpr int NTHREADS = TILE * WAVES;
 #ifndef APS_LIST_CAP
-#define APS_LIST_CAP 1024
+#define APS_LIST_CAP 256
 #endif
-constexpr int LIST_CAP = APS_LIST_CAP;        // active-tile work list entries per scan round
+constexpr int LIST_CAP = APS_LIST_CAP;        // in-kernel work list entries per scan round (overflow fallback only)
+constexpr int MAX_SPLIT = 16;                 // shares a target tile's source list can be cut into
+constexpr int PLAN_CAP = 192;                 // planned source tiles per target tile (more -> in-kernel scan)
 
 enum { EV_NONE = 0, EV_LEFT = 1, EV_RIGHT = 2, EV_FWD = 3, EV_BIND = 4, EV_UNBIND = 5, EV_EXIT = 6, EV_FLIP = 7 };
 enum { V_FAST = 0, V_GENERIC = 1, V_MIRROR = 2 };
@@ -115,23 +118,26 @@ struct PairArgs {
     const double *beta;       // [E]
     const uint8_t *anchor;    // [L] or nullptr
     uint8_t *prop;            // [world][E][SH]
-    uint32_t *pcnt;           // [E][L], zeroed here for the commit that follows
+    uint32_t *pcnt;           // [E][L], zeroed by propose() for the commit that follows
+    double *accW, *accS;      // [split][E][Npad] per-share partial sums (plain stores; propose() adds the shares)
+    unsigned *occ;            // [split][E][Npad] packed neighbour-site occupancies: own | left << 10 | right << 20
+    int split;                // shares per target tile
     double *S_out, *W_out;    // optional [E][Npad]
     int *occ4_out;            // optional [E][Npad][4]
-    unsigned long long *tiles_done;   // statistics: source tiles actually evaluated
     unsigned *work_ctr;       // next (ensemble, target tile) item; reset by apply()
     unsigned long long *stamps;   // diagnostic build only (APS_STAMPS): per-workgroup phase cycle totals
+    const uint32_t *plan_n;   // [E][ntiles] number of planned source tiles (> PLAN_CAP: overflow)
     int tlen, Npad, SH, E, ntiles, tile_lo, tile_cnt;
     uint32_t step_lo, step_hi;
     int write_prop;
 };
 
 // ------------------------------------------------------------------------------------ inner loops
-// d = |a - b| + c in ONE VALU op.  b is wave-uniform (SGPR); c carries the LDS byte offset of the table,
-// so the result is directly the LDS address of w(|dp|).
-__device__ __forceinline__ uint32_t sad_vsv(uint32_t a_vec, uint32_t b_uni, uint32_t c_vec) {
+// d = |a - b| + c in ONE VALU op; c carries the LDS byte offset of the table, so the result is directly the
+// LDS address of w(|dp|).
+__device__ __forceinline__ uint32_t sad3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
-    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a_vec), "s"(b_uni), "v"(c_vec));
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 
@@ -144,56 +150,33 @@ __device__ __forceinline__ double table_at(const double *__restrict__ table_g, u
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(table_g) + byte_addr);
 }
 
-// G sources (one scalar-loaded group) against this lane's target.  Sources arrive pre-decoded as
-// (site*8, high word of +-1.0) pairs through SCALAR loads (they are wave-uniform), so the scalar unit does
-// no per-source work; per pair the vector unit issues v_sad_u32 -> ds_read_b64 -> v_add_f64 -> v_fma_f64.
-//   V_FAST    every pair of the tile block is inside the table's reach and farther than one site: no clamp
-//   V_GENERIC clamp to the zero entry behind the table; track the smallest distance for the occupancy branch
-//   V_MIRROR  additionally the reflected images (distance p_i + p_j + 1 mod 2L)
 #ifndef APS_G
 #define APS_G 16
 #endif
-constexpr int G = APS_G;                      // sources per group (G/8 s_load_dwordx16)
+constexpr int G = APS_G;                      // sources per group = G/4 broadcast ds_read_b128
 constexpr int NACC = 4;                       // independent accumulator chains (sums are exact: order-free)
-struct Group { uint4 v[G / 2]; };             // {p8, sg_hi, p8, sg_hi} x 4
 
-__device__ __forceinline__ Group load_group(const uint2 *__restrict__ p) {
-    Group g;
-#ifdef APS_ABL_NOSMEM               /* timing-only ablation: synthesise the sources, no memory read */
-    const uint32_t b = (uint32_t)(size_t)p;
-#pragma unroll
-    for (int k = 0; k < G / 2; ++k) g.v[k] = make_uint4((b + 16u * k) & 0xFFFF8u, SG_PLUS, (b + 16u * k + 8u) & 0xFFFF8u, SG_MINUS);
-#else
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(p);
-#pragma unroll
-    for (int k = 0; k < G / 2; ++k) g.v[k] = t4[k];
-#endif
-    return g;
-}
-
+// G sources (already broadcast into registers: the same value in every lane) against this lane's target.
+// Per pair: v_sad_u32 -> ds_read_b64 (table gather) -> v_add_f64 (W) -> v_fma_f64 (S, sign from the wave mask).
+//   V_FAST    every pair of the tile block is inside the table's reach and farther than one site: no clamp
+//   V_GENERIC clamp to the zero entry behind the table; track the smallest distance for the occupancy branch
+//   V_MIRROR  additionally the reflected images (distance p_i + p_j + 1 mod 2L)
 template <int BC, int VAR, bool TAB_LDS>
-__device__ __forceinline__ void group_accumulate(const Group &grp, const uint32_t pi8, const uint32_t tbase,
+__device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const uint64_t signs, const uint32_t pi8, const uint32_t tbase,
                                                  const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
                                                  double (&accW)[NACC], double (&accS)[NACC], int &c0, int &cl, int &cr) {
-    uint32_t p8[G], sh[G];
-#pragma unroll
-    for (int k = 0; k < G / 2; ++k) {
-        p8[2 * k] = grp.v[k].x; sh[2 * k] = grp.v[k].y; p8[2 * k + 1] = grp.v[k].z; sh[2 * k + 1] = grp.v[k].w;
-    }
     uint32_t near = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < G; ++k) {
         double wt;
         if (VAR == V_FAST) {
 #if defined(APS_ABL_NOLDS)          /* timing-only ablations (wrong results): no table read at all */
-            wt = (double)sad_vsv(pi8, p8[k], tbase);
-#elif defined(APS_ABL_NOCONFLICT)   /* table read at a conflict-free address */
-            wt = table_at<TAB_LDS>(table_g, (sad_vsv(pi8, p8[k], tbase) & 0u) + tbase + ((threadIdx.x & 63u) << 3));
+            wt = (double)sad3(pi8, p8[k], tbase);
 #else
-            wt = table_at<TAB_LDS>(table_g, sad_vsv(pi8, p8[k], tbase));
+            wt = table_at<TAB_LDS>(table_g, sad3(pi8, p8[k], tbase));
 #endif
         } else {
-            const uint32_t d8 = sad_vsv(pi8, p8[k], 0u);
+            const uint32_t d8 = sad3(pi8, p8[k], 0u);
             const uint32_t t8 = (BC == 1) ? min(d8, L8 - d8) : d8;      // circular distance on the torus
             wt = table_at<TAB_LDS>(table_g, min(t8, tlen8) + tbase);
             if (VAR == V_MIRROR) {
@@ -204,7 +187,7 @@ __device__ __forceinline__ void group_accumulate(const Group &grp, const uint32_
         }
         accW[k % NACC] += wt;
 #ifndef APS_ABL_NOFMA
-        accS[k % NACC] = fma(wt, __hiloint2double((int)sh[k], 0), accS[k % NACC]);
+        accS[k % NACC] = fma(wt, __hiloint2double((signs >> k) & 1ull ? (int)SG_PLUS : (int)SG_MINUS, 0), accS[k % NACC]);
 #endif
     }
     if (VAR != V_FAST && near <= 8u) {                       // rare: same or neighbouring site -> occupancy
@@ -240,48 +223,86 @@ __device__ __forceinline__ int tile_variant(int tlo, int thi, const int4 sb, int
     return direct ? V_GENERIC : -1;
 }
 
-// Workgroup-cooperative accumulation for ONE tile of 64 targets (lane = target, every wave holds the same
-// targets).  All threads scan the tile-info array and append the source tiles that matter to a work list in
-// LDS; the waves then take list entries round-robin.  Returns this wave's partial sums.
+// One source tile against this lane's target.  `word` is the tile's source word of THIS lane (lane = source:
+// site*8 | spin-plus in bit 0, or the far sentinel for dead slots), fetched earlier by one coalesced vector
+// load.  The wave parks the 64 sites in its private LDS ring slot and reads them back 4 at a time with
+// broadcast ds_read_b128, so every lane holds every source; the spins become a wave mask by one ballot.
 template <int BC, bool TAB_LDS>
-__device__ __forceinline__ unsigned accumulate_targets(const uint2 *__restrict__ spair_e, const int4 *__restrict__ tinfo_e,
-                                                       const int ntiles, const int tlo, const int thi, const bool allow_fast,
-                                                       const uint32_t pi8,
-                                                       const uint32_t tbase, const double *__restrict__ table_g,
-                                                       const int tlen, const int L, uint32_t *list, uint32_t *ctl,
-                                                       const int wave, double &accW_out, double &accS_out, int &c0, int &cl, int &cr) {
+__device__ __forceinline__ void process_tile(const uint32_t var, const uint32_t word, uint32_t *ring, const uint32_t pi8,
+                                             const uint32_t tbase, const double *__restrict__ table_g, const uint32_t tlen8,
+                                             const uint32_t L8, double (&accW)[NACC], double (&accS)[NACC], int &c0, int &cl, int &cr) {
+    const uint64_t mask = __ballot((word & 1u) != 0u);
+    ring[threadIdx.x & 63] = word & ~7u;
+    const uint4 *ring4 = reinterpret_cast<const uint4 *>(ring);
+#pragma unroll 1
+    for (int g = 0; g < TILE; g += G) {
+        uint32_t p8[G];
+#pragma unroll
+        for (int k = 0; k < G / 4; ++k) {
+            const uint4 v = ring4[g / 4 + k];                // uniform address: LDS broadcast
+            p8[4 * k] = v.x; p8[4 * k + 1] = v.y; p8[4 * k + 2] = v.z; p8[4 * k + 3] = v.w;
+        }
+        if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS>(p8, mask >> g, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+        else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS>(p8, mask >> g, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+        else group_accumulate<BC, V_MIRROR, TAB_LDS>(p8, mask >> g, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+    }
+}
+
+// Accumulation of one work item by ONE wave: target tile (lane = target) against share `q` of `split` of its
+// source tiles.  Planned path: the wave's list entries are fetched with one vector load (lane k = k-th entry
+// of the share) and the source tiles are streamed one tile ahead (vmcnt), so no memory latency is exposed in
+// the steady state.  Overflow path (list longer than PLAN_CAP, e.g. unsorted particles): the wave scans the
+// tile infos itself, 64 at a time.  No barrier anywhere.
+template <int BC, bool TAB_LDS>
+__device__ __forceinline__ unsigned accumulate_item(const uint32_t *__restrict__ entries, const int pn, const int q, const int split,
+                                                    const uint32_t *__restrict__ sp8_e, const int4 *__restrict__ tinfo_e,
+                                                    const int ntiles, const int4 tb, const uint32_t pi8, const uint32_t tbase,
+                                                    uint32_t *ring, const double *__restrict__ table_g, const int tlen, const int L,
+                                                    double &accW_out, double &accS_out, int &c0, int &cl, int &cr) {
+    const uint32_t tlen8 = (uint32_t)tlen << 3, L8 = (uint32_t)L << 3;
+    const int lane = threadIdx.x & 63;
     double accW[NACC], accS[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) accW[k] = accS[k] = 0.0;
-    const uint32_t tlen8 = (uint32_t)tlen << 3, L8 = (uint32_t)L << 3;
-    const int R = tlen > 1 ? tlen - 1 : 1, Rtab = tlen - 1;
     unsigned done = 0;
-    for (int base = 0; base < ntiles; base += LIST_CAP) {
-        __syncthreads();                                     // previous round's list fully consumed
-        if (threadIdx.x == 0) ctl[1] = 0u;
-        __syncthreads();
-        const int end = min(base + LIST_CAP, ntiles);
-        for (int jt = base + (int)threadIdx.x; jt < end; jt += NTHREADS) {
-            const int var = tile_variant<BC>(tlo, thi, tinfo_e[jt], R, Rtab, L, allow_fast);
-            if (var >= 0) list[atomicAdd(&ctl[1], 1u)] = (uint32_t)jt | ((uint32_t)var << 28);
-        }
-        __syncthreads();
-        const int n = (int)ctl[1];
-#ifdef APS_ABL_NOACC
-        if (n >= 0) continue;
+    if (pn <= PLAN_CAP) {
+        const int cnt = pn > q ? (pn - q + split - 1) / split : 0;       // entries of this share
+        for (int c = 0; c < cnt; c += TILE) {
+            const int n = min(TILE, cnt - c);
+            const uint32_t my_ent = lane < n ? entries[q + (size_t)(c + lane) * split] : 0u;
+            uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)my_ent, 0);
+#ifdef APS_ABL_NOSRC                /* timing-only ablation: synthetic source words, no loads in the tile loop */
+#define APS_SRC(e_) ((((e_) & 0x0FFFFFFFu) * 1024u + (uint32_t)lane * 16u) | 1u)
+#else
+#define APS_SRC(e_) sp8_e[(size_t)((e_) & 0x0FFFFFFFu) * TILE + lane]
 #endif
-        for (int i = wave; i < n; i += WAVES) {
-            const uint32_t ent = __builtin_amdgcn_readfirstlane(list[i]);
-            const uint2 *__restrict__ tile = spair_e + (size_t)(ent & 0x0FFFFFFFu) * TILE;
-            const uint32_t var = ent >> 28;
-#pragma unroll 1
-            for (int g = 0; g < TILE; g += G) {
-                const Group grp = load_group(tile + g);
-                if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS>(grp, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
-                else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS>(grp, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
-                else group_accumulate<BC, V_MIRROR, TAB_LDS>(grp, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+            uint32_t nxt = APS_SRC(ent);
+            for (int k = 0; k < n; ++k) {
+                const uint32_t cur = nxt, var = ent >> 28;
+                if (k + 1 < n) {                             // next tile's sources are in flight during this tile
+                    ent = (uint32_t)__builtin_amdgcn_readlane((int)my_ent, k + 1);
+                    nxt = APS_SRC(ent);
+                }
+                process_tile<BC, TAB_LDS>(var, cur, ring, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+                ++done;
             }
-            ++done;
+        }
+    } else {
+        const int R = tlen > 1 ? tlen - 1 : 1, Rtab = tlen - 1;
+        unsigned seen = 0;
+        for (int base = 0; base < ntiles; base += 64) {
+            const int jt = base + lane;
+            const int var = jt < ntiles ? tile_variant<BC>(tb.x, tb.y, tinfo_e[jt], R, Rtab, L, tb.z == 0) : -1;
+            unsigned long long m = __ballot(var >= 0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                if ((int)(seen++ % (unsigned)split) != q) continue;
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(var, b);
+                process_tile<BC, TAB_LDS>(v, sp8_e[(size_t)(base + b) * TILE + lane], ring, pi8, tbase, table_g, tlen8, L8,
+                                          accW, accS, c0, cl, cr);
+                ++done;
+            }
         }
     }
 #pragma unroll
@@ -290,11 +311,21 @@ __device__ __forceinline__ unsigned accumulate_targets(const uint2 *__restrict__
     return done;
 }
 
-// LDS carve-up shared by both kernels: [table (tlen+1) doubles][partials (WAVES-1)*64*4 doubles][list][ctl]
-__host__ __device__ inline size_t lds_table_doubles(int tlen, bool tab_lds) { return tab_lds ? (size_t)tlen + 1 : 0; }
-__host__ __device__ inline size_t lds_total_bytes(int tlen, bool tab_lds) {
-    return (lds_table_doubles(tlen, tab_lds) + (size_t)(WAVES - 1) * TILE * 4) * sizeof(double) + (LIST_CAP + 4) * sizeof(uint32_t);
+// Weight table global -> LDS with 8 independent loads in flight per thread (a plain loop waits for each load).
+__device__ __forceinline__ void stage_table(double *lds, const double *__restrict__ table_g, const int tlen) {
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base <= tlen; base += NTHREADS * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = base + u * NTHREADS; v[u] = i <= tlen ? table_g[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = base + u * NTHREADS; if (i <= tlen) lds[i] = v[u]; }
+    }
 }
+
+// LDS holds only the weight table (tlen + 1 doubles) when it fits
+__host__ __device__ inline size_t lds_table_bytes(int tlen, bool tab_lds) { return tab_lds ? ((size_t)tlen + 2) / 2 * 2 * sizeof(double) : 0; }
+__host__ __device__ inline size_t lds_total_bytes(int tlen, bool tab_lds) { return lds_table_bytes(tlen, tab_lds) + (size_t)WAVES * TILE * sizeof(uint32_t); }
 
 struct Channels { double diff, act, flip, bind, unbind, leave, left, right, total; };
 
@@ -337,156 +368,205 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
     return c;
 }
 
-// Persistent workgroups: each pulls (ensemble, target tile) items from an atomic counter, so the weight
-// table is staged into LDS once per workgroup and the grid has no tail.  The read-only arrays are separate
-// `const __restrict__` kernel parameters (not struct members) so the compiler can prove the wave-uniform
-// source reads are never clobbered and emits scalar loads for them.
+// plan<BC>: one wave per target tile lists the source tiles that can matter (tile index | loop variant << 28)
+// into plan[e][t][0..PLAN_CAP) and their number into plan_n[e][t] (a count > PLAN_CAP means "scan in-kernel").
+// Correct for any particle order; short lists when the slots are site-sorted.
+struct PlanArgs { int L, tlen, ntiles, tile_lo, tile_cnt; uint32_t *plan, *plan_n; };
+
+template <int BC>
+__global__ __launch_bounds__(256) void plan_tiles(const PlanArgs a, const int4 *__restrict__ tinfo_all) {
+    const int e = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tt >= a.tile_cnt) return;
+    const int ttile = a.tile_lo + tt;
+    const int4 *__restrict__ tinfo_e = tinfo_all + (size_t)e * a.ntiles;
+    const int4 tb = tinfo_e[ttile];
+    uint32_t *out = a.plan + ((size_t)e * a.ntiles + ttile) * PLAN_CAP;
+    const int R = a.tlen > 1 ? a.tlen - 1 : 1, Rtab = a.tlen - 1;
+    unsigned n = 0;
+    if (tb.w > 0) {
+        constexpr int U = 8;                                  // independent tile-info loads in flight per lane
+        for (int base = 0; base < a.ntiles; base += 64 * U) {
+            int4 info[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jt = base + u * 64 + lane;
+                info[u] = jt < a.ntiles ? tinfo_e[jt] : make_int4(0, -1, 1, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jt = base + u * 64 + lane;
+                const int var = jt < a.ntiles ? tile_variant<BC>(tb.x, tb.y, info[u], R, Rtab, a.L, tb.z == 0) : -1;
+                const unsigned long long m = __ballot(var >= 0);
+                if (var >= 0) {
+                    const unsigned k = n + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (k < (unsigned)PLAN_CAP) out[k] = (uint32_t)jt | ((uint32_t)var << 28);
+                }
+                n += (unsigned)__popcll(m);
+            }
+        }
+    }
+    if (lane == 0) a.plan_n[(size_t)e * a.ntiles + ttile] = n;
+}
+
+// pair_accumulate: the dominant kernel.  Persistent workgroups of 4 INDEPENDENT waves that share only the
+// weight table in LDS.  Wave w evaluates the work items w, w + nwaves, w + 2 nwaves, ...  Item = (ensemble, target tile, share q of `split`): 64 targets (lane = target) against every
+// split-th source tile of the target tile's list.  The partial sums go to the per-particle accumulators with
+// atomics: sums of weights are exact on the 2^-q grid, so the result does not depend on the arrival order.
+// The read-only arrays are separate `const __restrict__` kernel parameters (not struct members) so the
+// compiler can prove the wave-uniform reads are never clobbered and emits scalar loads.
 template <int BC, bool TAB_LDS>
-__global__ __launch_bounds__(NTHREADS) void pair_propose(const PairArgs a, const uint2 *__restrict__ spair_all,
-                                                        const int4 *__restrict__ tinfo_all,
-                                                        const double *__restrict__ table_g) {
+__global__ __launch_bounds__(NTHREADS) void pair_accumulate(const PairArgs a, const uint32_t *__restrict__ sp8_all,
+                                                           const uint64_t *__restrict__ smask_all,
+                                                           const int4 *__restrict__ tinfo_all,
+                                                           const double *__restrict__ table_g,
+                                                           const uint32_t *__restrict__ plan_all,
+                                                           const uint32_t *__restrict__ plan_n_all) {
     extern __shared__ double lds[];
     const Model &M = a.m;
     const int lane = threadIdx.x & (TILE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // the commit that follows this launch needs empty per-site proposer counters
-    {
-        const size_t total = (size_t)a.E * (size_t)M.L;
-        const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) a.pcnt[i] = 0u;
-    }
-
-    const size_t tdoubles = lds_table_doubles(a.tlen, TAB_LDS);
-    double *part = lds + tdoubles;                            // [(WAVES-1)][TILE][4] partial sums
-    uint32_t *list = reinterpret_cast<uint32_t *>(part + (size_t)(WAVES - 1) * TILE * 4);
-    uint32_t *ctl = list + LIST_CAP;
     uint32_t tbase = 0;
     if (TAB_LDS) {
-        for (int i = threadIdx.x; i <= a.tlen; i += NTHREADS) lds[i] = table_g[i];
+        stage_table(lds, table_g, a.tlen);
         typedef __attribute__((address_space(3))) double lds_double;
         tbase = (uint32_t)(size_t)(lds_double *)lds;          // LDS byte offset of the table
+        __syncthreads();
     }
-    const unsigned total_items = (unsigned)a.E * (unsigned)a.tile_cnt;
+    uint32_t *ring = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + lds_table_bytes(a.tlen, TAB_LDS)) + wave * TILE;
+    const unsigned total_items = (unsigned)a.E * (unsigned)a.tile_cnt * (unsigned)a.split;
+    const unsigned nwaves = gridDim.x * WAVES;
 #ifdef APS_STAMPS
     unsigned long long t_fetch = 0, t_acc = 0, t_epi = 0, t_items = 0, t0 = __builtin_amdgcn_s_memtime(), t_start = t0;
+    const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();
 #define STAMP(var) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - t0; t0 = t1_; }
 #else
 #define STAMP(var)
 #endif
-
-    for (;;) {
-        __syncthreads();                                      // ctl[0] / partials of the previous item are consumed
-        if (threadIdx.x == 0) ctl[0] = atomicAdd(a.work_ctr, 1u);
-        __syncthreads();
-        const unsigned item = ctl[0];
-        STAMP(t_fetch)
-        if (item >= total_items) break;
-        const int e = (int)(item / (unsigned)a.tile_cnt);
-        const int ttile = a.tile_lo + (int)(item % (unsigned)a.tile_cnt);
-        const uint2 *__restrict__ spair_e = spair_all + (size_t)e * a.Npad;
+    unsigned item = blockIdx.x * WAVES + wave;                // static first item: no stampede on the counter
+    while (item < total_items) {
+        const int q = (int)(item % (unsigned)a.split);
+        const unsigned tix = item / (unsigned)a.split;
+        const int e = (int)(tix / (unsigned)a.tile_cnt);
+        const int ttile = a.tile_lo + (int)(tix % (unsigned)a.tile_cnt);
+        const uint32_t *__restrict__ sp8_e = sp8_all + (size_t)e * a.Npad;
         const int4 *__restrict__ tinfo_e = tinfo_all + (size_t)e * a.ntiles;
         const size_t slot = (size_t)ttile * TILE + lane;
-        const uint32_t pi8 = spair_e[slot].x == DEAD_P8 ? 0u : spair_e[slot].x;   // dead targets: any in-range site
+        const uint32_t my_p8 = sp8_e[slot] & ~7u;
+        const uint32_t pi8 = my_p8 == DEAD_P8 ? 0u : my_p8;  // dead targets: any in-range site
         const int4 tb = tinfo_e[ttile];
-
+        const int pn = (int)plan_n_all[(size_t)e * a.ntiles + ttile];
+        STAMP(t_fetch)
         double accW = 0.0, accS = 0.0;
         int c0 = 0, cl = 0, cr = 0;
         unsigned done = 0;
         if (tb.w > 0)
-            done = accumulate_targets<BC, TAB_LDS>(spair_e, tinfo_e, a.ntiles, tb.x, tb.y, tb.z == 0, pi8, tbase, table_g, a.tlen, M.L,
-                                                   list, ctl, wave, accW, accS, c0, cl, cr);
-        if (lane == 0 && done && a.tiles_done) atomicAdd(a.tiles_done, (unsigned long long)done);
+            done = accumulate_item<BC, TAB_LDS>(plan_all + ((size_t)e * a.ntiles + ttile) * PLAN_CAP, pn, q, a.split, sp8_e,
+                                                tinfo_e, a.ntiles, tb, pi8, tbase, ring, table_g, a.tlen, M.L, accW, accS, c0, cl, cr);
         STAMP(t_acc)
+#ifdef APS_ABL_NOSTORE
+        if (accW == -1.0)
+#endif
+        {   // every (tile, share) item is evaluated exactly once per launch: plain stores, nothing to clear
+            const size_t o = ((size_t)q * a.E + e) * a.Npad + slot;
+            a.accW[o] = accW; a.accS[o] = accS;
+            a.occ[o] = (unsigned)c0 | ((unsigned)cl << 10) | ((unsigned)cr << 20);
+        }
+        item += nwaves;                                       // static striding: items cost about the same, and a single
+        STAMP(t_epi)                                          // dequeue counter saturates at ~88 grabs/us (measured)
 #ifdef APS_STAMPS
         t_items += 1;
 #endif
-
-        // combine the waves' partial sums (exact on the weight grid, so the order is irrelevant)
-        if (wave != 0) {
-            double *mine = part + ((size_t)(wave - 1) * TILE + lane) * 4;
-            mine[0] = accW; mine[1] = accS;
-            reinterpret_cast<int *>(mine + 2)[0] = c0; reinterpret_cast<int *>(mine + 2)[1] = cl;
-            reinterpret_cast<int *>(mine + 3)[0] = cr;
-        }
-        __syncthreads();
-        if (wave != 0) continue;
-        for (int w = 0; w < WAVES - 1; ++w) {
-            const double *o = part + ((size_t)w * TILE + lane) * 4;
-            accW += o[0]; accS += o[1];
-            c0 += reinterpret_cast<const int *>(o + 2)[0]; cl += reinterpret_cast<const int *>(o + 2)[1];
-            cr += reinterpret_cast<const int *>(o + 3)[0];
-        }
-
-        // ---------------- epilogue: one lane = one target particle
-        const uint32_t me = a.src[(size_t)e * a.Npad + slot];
-        const bool live = !(me & DEAD_BIT);
-        const int p = (int)(me & POS_MASK);
-        const int spin = (me & SPIN_BIT) ? 1 : -1;
-        const bool bound = (me & BOUND_BIT) != 0;
-        if (M.field_mode == 0) {                              // global mean field (ref :219-221)
-            accS = (double)a.gsum[2 * e]; accW = (double)a.gsum[2 * e + 1];
-        }
-        if (!live) { accS = 0.0; accW = 0.0; c0 = cl = cr = 0; }
-        const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == M.L - 1;
-        if (a.S_out) {
-            a.S_out[(size_t)e * a.Npad + slot] = accS;
-            a.W_out[(size_t)e * a.Npad + slot] = accW;
-            int *o = a.occ4_out + ((size_t)e * a.Npad + slot) * 4;
-            const int o_l = wall_l ? c0 : cl, o_r = wall_r ? c0 : cr;
-            o[0] = c0; o[1] = live ? (spin > 0 ? o_r : c0) : 0; o[2] = live ? o_l : 0; o[3] = live ? o_r : 0;
-        }
-        if (!a.write_prop) continue;
-        uint8_t code = EV_NONE;
-        if (live) {
-            double mloc = 0.0;
-            if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
-            const bool anch = a.anchor ? a.anchor[p] != 0 : false;
-            const Channels c = channels(M, anch, p, spin, bound, mloc, a.beta[e], c0, cl, cr);
-            uint32_t x[4];
-            philox4x32_10(a.step_lo, a.step_hi, a.orig[(size_t)e * a.Npad + slot], (uint32_t)(M.ens_base + e),
-                          M.seed_lo, M.seed_hi, x);
-            const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
-            const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
-            const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
-            if (u0 < p_fire) {
-                const double v = u1 * c.total;
-                const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
-                             e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
-                int ev = EV_NONE, occ_t = 0;
-                if (v < e_diff) {
-                    if (c.left + c.right > 0.0) {
-                        if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
-                        else { ev = EV_RIGHT; occ_t = cr; }
-                    }
-                } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
-                else if (v < e_bind) ev = EV_BIND;
-                else if (v < e_unbind) ev = EV_UNBIND;
-                else if (v < e_exit) ev = EV_EXIT;
-                else ev = EV_FLIP;
-                int cap = M.K - occ_t;                       // free capacity of the hop target at step start
-                cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
-                code = (uint8_t)(ev | ((cap - 1) << 3));
-            }
-        }
-        const int r = (int)(slot / a.SH);
-        a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
-        STAMP(t_epi)
     }
 #ifdef APS_STAMPS
     if (threadIdx.x == 0 && a.stamps) {
         unsigned long long *o = a.stamps + (size_t)blockIdx.x * 8;
         o[0] = t_fetch; o[1] = t_acc; o[2] = t_epi; o[3] = t_items; o[4] = __builtin_amdgcn_s_memtime() - t_start;
-        o[5] = __builtin_amdgcn_s_memrealtime();
+        o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = r_start;
     }
 #endif
+}
+
+// propose: per-particle epilogue of the step (rates -> Philox draw -> proposal byte), one thread per slot of
+// this rank's shard.  Consumes and clears the accumulators; also clears the per-site proposer counters for
+// the commit that follows and resets the work counter.
+__global__ __launch_bounds__(256) void propose(const PairArgs a) {
+    const Model &M = a.m;
+    const int e = blockIdx.y;
+    {
+        const size_t total = (size_t)M.L, nthreads = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) a.pcnt[(size_t)e * M.L + i] = 0u;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.work_ctr = 0u;
+    const size_t slot = (size_t)a.tile_lo * TILE + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (size_t)(a.tile_lo + a.tile_cnt) * TILE) return;
+    const size_t o = (size_t)e * a.Npad + slot;
+    double accW = 0.0, accS = 0.0;
+    unsigned packed = 0;
+    for (int q = 0; q < a.split; ++q) {                       // exact sums: the order of the shares is irrelevant
+        const size_t oq = ((size_t)q * a.E + e) * a.Npad + slot;
+        accW += a.accW[oq]; accS += a.accS[oq]; packed += a.occ[oq];
+    }
+    int c0 = packed & 1023, cl = (packed >> 10) & 1023, cr = (packed >> 20) & 1023;
+    const uint32_t me = a.src[o];
+    const bool live = !(me & DEAD_BIT);
+    const int p = (int)(me & POS_MASK);
+    const int spin = (me & SPIN_BIT) ? 1 : -1;
+    const bool bound = (me & BOUND_BIT) != 0;
+    if (M.field_mode == 0) {                                  // global mean field (ref :219-221)
+        accS = (double)a.gsum[2 * e]; accW = (double)a.gsum[2 * e + 1];
+    }
+    if (!live) { accS = 0.0; accW = 0.0; c0 = cl = cr = 0; }
+    const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == M.L - 1;
+    if (a.S_out) {
+        a.S_out[o] = accS;
+        a.W_out[o] = accW;
+        int *oo = a.occ4_out + o * 4;
+        const int o_l = wall_l ? c0 : cl, o_r = wall_r ? c0 : cr;
+        oo[0] = c0; oo[1] = live ? (spin > 0 ? o_r : c0) : 0; oo[2] = live ? o_l : 0; oo[3] = live ? o_r : 0;
+    }
+    if (!a.write_prop) return;
+    uint8_t code = EV_NONE;
+    if (live) {
+        double mloc = 0.0;
+        if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+        const bool anch = a.anchor ? a.anchor[p] != 0 : false;
+        const Channels c = channels(M, anch, p, spin, bound, mloc, a.beta[e], c0, cl, cr);
+        uint32_t x[4];
+        philox4x32_10(a.step_lo, a.step_hi, a.orig[o], (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, x);
+        const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
+        const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
+        const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
+        if (u0 < p_fire) {
+            const double v = u1 * c.total;
+            const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
+                         e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
+            int ev = EV_NONE, occ_t = 0;
+            if (v < e_diff) {
+                if (c.left + c.right > 0.0) {
+                    if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
+                    else { ev = EV_RIGHT; occ_t = cr; }
+                }
+            } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
+            else if (v < e_bind) ev = EV_BIND;
+            else if (v < e_unbind) ev = EV_UNBIND;
+            else if (v < e_exit) ev = EV_EXIT;
+            else ev = EV_FLIP;
+            int cap = M.K - occ_t;                           // free capacity of the hop target at step start
+            cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
+            code = (uint8_t)(ev | ((cap - 1) << 3));
+        }
+    }
+    const int r = (int)(slot / a.SH);
+    a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
 }
 
 // ---------------------------------------------------------------------------------------------
 struct CommitArgs {
     Model m;
     uint32_t *src; const uint32_t *orig; const uint8_t *prop;
-    uint2 *spair; int4 *tinfo;
+    uint32_t *sp8; unsigned long long *smask; int4 *tinfo;
     uint32_t *pcnt, *plist; long long *gsum;
     double *exit_log; unsigned *n_exit; int exit_cap;
     unsigned *work_ctr;
@@ -551,8 +631,8 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     }
     // pre-decoded source pair for the next all-pairs pass, per-tile (= per-wave) info, global spin sums
     const bool live = !(me & DEAD_BIT);
-    if (ev != EV_NONE)
-        a.spair[(size_t)e * a.Npad + slot] = make_uint2(live ? (uint32_t)p << 3 : DEAD_P8, (me & SPIN_BIT) ? SG_PLUS : SG_MINUS);
+    if (ev != EV_NONE) a.sp8[(size_t)e * a.Npad + slot] = live ? (((uint32_t)p << 3) | ((me & SPIN_BIT) ? 1u : 0u)) : DEAD_P8;
+    const unsigned long long plus_mask = __ballot(live && (me & SPIN_BIT));
     int lo = live ? p : 0x7fffffff, hi = live ? p : -1;
     int ssum = live ? ((me & SPIN_BIT) ? 1 : -1) : 0, cnt = live ? 1 : 0;
 #pragma unroll
@@ -562,6 +642,7 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     }
     if ((threadIdx.x & 63) == 0) {
         a.tinfo[(size_t)e * a.ntiles + slot / TILE] = make_int4(lo, hi, cnt < TILE ? 1 : 0, cnt);
+        a.smask[(size_t)e * a.ntiles + slot / TILE] = plus_mask;
         if (a.m.field_mode == 0 && cnt) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e]), (unsigned long long)(long long)ssum);
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e + 1]), (unsigned long long)cnt);
@@ -576,37 +657,32 @@ struct FieldArgs {
 };
 
 template <int BC, bool TAB_LDS>
-__global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const uint2 *__restrict__ spair,
+__global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const uint32_t *__restrict__ sp8,
+                                                       const uint64_t *__restrict__ smask,
                                                        const int4 *__restrict__ tinfo,
                                                        const double *__restrict__ table_g) {
     extern __shared__ double lds[];
     const Model &M = a.m;
     const int lane = threadIdx.x & (TILE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t tdoubles = lds_table_doubles(a.tlen, TAB_LDS);
-    double *part = lds + tdoubles;
-    uint32_t *list = reinterpret_cast<uint32_t *>(part + (size_t)(WAVES - 1) * TILE * 4);
-    uint32_t *ctl = list + LIST_CAP;
     uint32_t tbase = 0;
     if (TAB_LDS) {
-        for (int i = threadIdx.x; i <= a.tlen; i += NTHREADS) lds[i] = table_g[i];
+        stage_table(lds, table_g, a.tlen);
         typedef __attribute__((address_space(3))) double lds_double;
         tbase = (uint32_t)(size_t)(lds_double *)lds;
+        __syncthreads();
     }
-    const int x = blockIdx.x * TILE + lane;
-    const int tlo = blockIdx.x * TILE, thi = min(tlo + TILE - 1, M.L - 1);
+    uint32_t *ring = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + lds_table_bytes(a.tlen, TAB_LDS)) + wave * TILE;
+    const int tlo = (blockIdx.x * WAVES + wave) * TILE;       // one wave = 64 consecutive sites
+    if (tlo >= M.L) return;
+    const int thi = min(tlo + TILE - 1, M.L - 1);
+    const int x = tlo + lane;
     const uint32_t pi8 = (uint32_t)min(x, M.L - 1) << 3;
     double accW = 0.0, accS = 0.0;
     int c0 = 0, cl = 0, cr = 0;
-    accumulate_targets<BC, TAB_LDS>(spair, tinfo, a.ntiles, tlo, thi, true, pi8, tbase, table_g, a.tlen, M.L, list, ctl, wave,
-                                    accW, accS, c0, cl, cr);
-    if (wave != 0) {
-        double *mine = part + ((size_t)(wave - 1) * TILE + lane) * 4;
-        mine[0] = accW; mine[1] = accS;
-    }
-    __syncthreads();
-    if (wave != 0 || x >= M.L) return;
-    for (int w = 0; w < WAVES - 1; ++w) { accW += part[((size_t)w * TILE + lane) * 4]; accS += part[((size_t)w * TILE + lane) * 4 + 1]; }
+    accumulate_item<BC, TAB_LDS>(nullptr, PLAN_CAP + 1, 0, 1, sp8, tinfo, a.ntiles, make_int4(tlo, thi, 0, TILE), pi8, tbase, ring,
+                                 table_g, a.tlen, M.L, accW, accS, c0, cl, cr);
+    if (x >= M.L) return;
     if (M.field_mode == 0) { accS = (double)a.gsum[2 * a.e]; accW = (double)a.gsum[2 * a.e + 1]; }
     double mloc = 0.0;
     if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
@@ -632,10 +708,16 @@ struct aps_handle {
     bool own_stream = false;
     uint32_t *d_src = nullptr, *d_orig = nullptr, *d_pcnt = nullptr, *d_plist = nullptr;
     uint8_t *d_prop = nullptr, *d_prop_own = nullptr, *d_anchor = nullptr;
-    uint2 *d_spair = nullptr;
+    uint32_t *d_sp8 = nullptr;
+    unsigned long long *d_smask = nullptr;
     int4 *d_tinfo = nullptr;
     unsigned *d_work_ctr = nullptr;
     unsigned long long *d_stamps = nullptr;
+    uint32_t *d_plan = nullptr, *d_plan_n = nullptr;
+    double *d_accW = nullptr, *d_accS = nullptr;
+    unsigned *d_occ = nullptr;
+    int split = 1;
+    bool plan_dirty = true;
     bool ctr_dirty = true;
     int num_cu = 256, wgs_per_cu = 1;
     double *d_table = nullptr, *d_beta = nullptr, *d_exit = nullptr, *d_S = nullptr, *d_W = nullptr, *d_mfield = nullptr;
@@ -643,7 +725,7 @@ struct aps_handle {
     long long *d_gsum = nullptr;
     unsigned *d_nexit = nullptr;
     unsigned long long *d_tiles = nullptr;
-    uint2 *d_tmp_spair = nullptr; int4 *d_tmp_tinfo = nullptr; size_t tmp_cap = 0;
+    uint32_t *d_tmp_sp8 = nullptr; unsigned long long *d_tmp_smask = nullptr; int4 *d_tmp_tinfo = nullptr; size_t tmp_cap = 0;
     int exit_cap = 0;
     int64_t step = 0;
     std::vector<int64_t> n_set;    // particles uploaded per ensemble
@@ -720,16 +802,19 @@ int dev_alloc(aps_handle *h, T **ptr, size_t count) {
     return APS_OK;
 }
 
-// per-tile info and pre-decoded source pairs of a slot array (host mirror of what apply() maintains)
-void derive_sources(const std::vector<uint32_t> &src, std::vector<uint2> &spair, std::vector<int4> &tinfo) {
+// per-tile info, spin masks and pre-decoded source words of a slot array (host mirror of what apply() maintains)
+void derive_sources(const std::vector<uint32_t> &src, std::vector<uint32_t> &sp8, std::vector<unsigned long long> &smask,
+                    std::vector<int4> &tinfo) {
     const size_t n = src.size(), nt = n / TILE;
-    spair.resize(n);
+    sp8.resize(n);
+    smask.assign(nt, 0ull);
     tinfo.assign(nt, make_int4(0x7fffffff, -1, 1, 0));
     for (size_t s = 0; s < n; ++s) {
         const uint32_t w = src[s];
         const bool live = !(w & DEAD_BIT);
-        spair[s] = make_uint2(live ? (w & POS_MASK) << 3 : DEAD_P8, (w & SPIN_BIT) ? SG_PLUS : SG_MINUS);
+        sp8[s] = live ? (((w & POS_MASK) << 3) | ((w & SPIN_BIT) ? 1u : 0u)) : DEAD_P8;
         if (!live) continue;
+        if (w & SPIN_BIT) smask[s / TILE] |= 1ull << (s % TILE);
         int4 &t = tinfo[s / TILE];
         const int p = (int)(w & POS_MASK);
         t.x = std::min(t.x, p); t.y = std::max(t.y, p); t.w += 1;
@@ -767,23 +852,25 @@ void pack_ensemble(const aps_handle *h, const int32_t *pos, const int8_t *sigma,
 }
 
 int upload_ensemble(aps_handle *h, int e, const std::vector<uint32_t> &src, const std::vector<uint32_t> &orig) {
-    std::vector<uint2> spair; std::vector<int4> tinfo;
-    derive_sources(src, spair, tinfo);
+    std::vector<uint32_t> sp8; std::vector<unsigned long long> smask; std::vector<int4> tinfo;
+    derive_sources(src, sp8, smask, tinfo);
     HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_spair + (size_t)e * h->Npad, spair.data(), spair.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sp8 + (size_t)e * h->Npad, sp8.data(), sp8.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_smask + (size_t)e * h->ntiles, smask.data(), smask.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tinfo + (size_t)e * h->ntiles, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->plan_dirty = true;
     return APS_OK;
 }
 
 PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
     PairArgs a{};
     a.m = h->model;
-    a.src = h->d_src; a.orig = h->d_orig; a.gsum = h->d_gsum; a.work_ctr = h->d_work_ctr; a.stamps = h->d_stamps;
+    a.src = h->d_src; a.orig = h->d_orig; a.gsum = h->d_gsum; a.work_ctr = h->d_work_ctr; a.stamps = h->d_stamps; a.plan_n = h->d_plan_n;
+    a.accW = h->d_accW; a.accS = h->d_accS; a.occ = h->d_occ; a.split = h->split;
     a.beta = h->d_beta; a.anchor = h->d_anchor; a.prop = h->d_prop; a.pcnt = h->d_pcnt;
     a.S_out = hook ? h->d_S : nullptr; a.W_out = hook ? h->d_W : nullptr; a.occ4_out = hook ? h->d_occ4 : nullptr;
-    a.tiles_done = h->d_tiles;
     a.tlen = h->tlen; a.Npad = (int)h->Npad; a.SH = (int)h->SH; a.E = h->E; a.ntiles = (int)h->ntiles;
     a.tile_lo = (int)(h->rank * h->SH / TILE); a.tile_cnt = (int)(h->SH / TILE);
     a.step_lo = (uint32_t)h->step; a.step_hi = (uint32_t)((uint64_t)h->step >> 32);
@@ -791,18 +878,47 @@ PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
     return a;
 }
 
+int launch_plan(aps_handle *h, int first_tile, int tile_cnt) {
+    PlanArgs pa{h->p.L, h->tlen, (int)h->ntiles, first_tile, tile_cnt, h->d_plan, h->d_plan_n};
+    const dim3 grid((unsigned)((tile_cnt + 3) / 4), (unsigned)h->E), block(256);
+    if (h->p.periodic) hipLaunchKernelGGL(plan_tiles<1>, grid, block, 0, h->stream, pa, h->d_tinfo);
+    else hipLaunchKernelGGL(plan_tiles<0>, grid, block, 0, h->stream, pa, h->d_tinfo);
+    HIP_TRY(h, hipGetLastError());
+    return APS_OK;
+}
+
 int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) {
     PairArgs b = a;
     b.tile_lo = first_tile; b.tile_cnt = tile_cnt;
+    const int shard_lo = (int)(h->rank * h->SH / TILE), shard_cnt = (int)(h->SH / TILE);
+    if (h->plan_dirty || first_tile != shard_lo || tile_cnt != shard_cnt) {     // hook launches cover every tile
+        int rc = launch_plan(h, first_tile, tile_cnt);
+        if (rc) return rc;
+        h->plan_dirty = (first_tile != shard_lo || tile_cnt != shard_cnt);
+    }
     if (h->ctr_dirty) HIP_TRY(h, hipMemsetAsync(h->d_work_ctr, 0, sizeof(unsigned), h->stream));
-    h->ctr_dirty = true;                                    // apply() resets the counter; until then it is spent
-    const unsigned items = (unsigned)tile_cnt * (unsigned)h->E;
-    const dim3 grid(std::max(1u, std::min(items, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
+    h->ctr_dirty = false;                                   // propose() resets the counter after use
+    // Shares per target tile.  Items are dealt to the resident waves round-robin, so pick the split whose
+    // item count fills whole rounds best (smallest idle fraction in the last round), with >= 2 rounds if possible.
+    const unsigned slots = (unsigned)(h->num_cu * h->wgs_per_cu * WAVES);
+    int split = 1;
+    double best = 1e30;
+    for (int sp = 1; sp <= MAX_SPLIT; ++sp) {
+        const double items = (double)tile_cnt * h->E * sp, rounds = std::ceil(items / slots);
+        const double cost = rounds * slots / items * (1.0 + 0.02 * sp) * (rounds < 2 ? 1.5 : 1.0);   // waste x mild per-item overhead
+        if (cost < best) { best = cost; split = sp; }
+    }
+    if (const char *env = std::getenv("APS_SPLIT")) split = std::max(1, std::min(MAX_SPLIT, std::atoi(env)));   // tuning knob
+    b.split = h->split = split;
+    const unsigned items = (unsigned)tile_cnt * (unsigned)h->E * (unsigned)split;
+    const dim3 grid(std::max(1u, std::min((items + WAVES - 1) / WAVES, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_propose<BC, TL>), grid, block, lds, h->stream, b, h->d_spair, h->d_tinfo, h->d_table)
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_accumulate<BC, TL>), grid, block, lds, h->stream, b, h->d_sp8, reinterpret_cast<const uint64_t *>(h->d_smask), h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
+    const dim3 pgrid((unsigned)((tile_cnt * TILE + 255) / 256), (unsigned)h->E);
+    hipLaunchKernelGGL(propose, pgrid, dim3(256), 0, h->stream, b);
     HIP_TRY(h, hipGetLastError());
     return APS_OK;
 }
@@ -810,7 +926,7 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
 CommitArgs commit_args(aps_handle *h) {
     CommitArgs c{};
     c.m = h->model; c.src = h->d_src; c.orig = h->d_orig; c.prop = h->d_prop; c.pcnt = h->d_pcnt;
-    c.spair = h->d_spair; c.tinfo = h->d_tinfo; c.work_ctr = h->d_work_ctr;
+    c.sp8 = h->d_sp8; c.smask = h->d_smask; c.tinfo = h->d_tinfo; c.work_ctr = h->d_work_ctr;
     c.plist = h->d_plist; c.gsum = h->d_gsum; c.exit_log = h->d_exit;
     c.n_exit = h->d_nexit; c.exit_cap = h->exit_cap; c.Npad = (int)h->Npad; c.SH = (int)h->SH; c.E = h->E;
     c.ntiles = (int)h->ntiles; c.step_as_double = (double)h->step;
@@ -822,26 +938,27 @@ int set_lds_limit(aps_handle *h) {
     const size_t need = lds_total_bytes(h->tlen, h->table_in_lds);
     if (need > 48 * 1024) {
         const int n = (int)need;
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_propose<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_propose<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_accumulate<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_accumulate<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
     }
     hipDeviceProp_t prop;
     HIP_TRY(h, hipGetDeviceProperties(&prop, h->p.device));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const int by_lds = (int)((160 * 1024) / need), by_waves = 32 / WAVES;
+    const int by_lds = need ? (int)((160 * 1024) / need) : 8, by_waves = 16 / WAVES;   // 4 waves/SIMD saturate the LDS gather
     h->wgs_per_cu = std::max(1, std::min(by_lds, by_waves));
+    if (const char *env = std::getenv("APS_WGS_PER_CU")) h->wgs_per_cu = std::max(1, std::atoi(env));     // tuning knob
     return APS_OK;
 }
 
-int launch_field(aps_handle *h, int e, const uint2 *spair, const int4 *tinfo, int ntiles, double *m_out) {
+int launch_field(aps_handle *h, int e, const uint32_t *sp8, const unsigned long long *smask, const int4 *tinfo, int ntiles, double *m_out) {
     FieldArgs f{};
     f.m = h->model; f.gsum = h->d_gsum; f.m_out = m_out;
     f.tlen = h->tlen; f.ntiles = ntiles; f.e = e;
-    const dim3 grid((unsigned)((h->p.L + TILE - 1) / TILE)), block(NTHREADS);
+    const dim3 grid((unsigned)((h->p.L + TILE * WAVES - 1) / (TILE * WAVES))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, spair, tinfo, h->d_table)
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, sp8, reinterpret_cast<const uint64_t *>(smask), tinfo, h->d_table)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
@@ -860,8 +977,10 @@ int do_commit(aps_handle *h) {
     hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);
     hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
     HIP_TRY(h, hipGetLastError());
-    h->ctr_dirty = false;                                   // claim() reset the work counter
     h->step += 1;
+    int rc = launch_plan(h, (int)(h->rank * h->SH / TILE), (int)(h->SH / TILE));   // source-tile lists of the new state
+    if (rc) return rc;
+    h->plan_dirty = false;
     return APS_OK;
 }
 
@@ -927,8 +1046,12 @@ int aps_create(const aps_params *p, aps_handle **out) {
     const size_t EN = (size_t)h->E * (size_t)h->Npad, EL = (size_t)h->E * (size_t)p->L;
     h->exit_cap = (int)std::max<int64_t>(h->N, 1);
     if ((rc = dev_alloc(h, &h->d_src, EN)) || (rc = dev_alloc(h, &h->d_orig, EN)) || (rc = dev_alloc(h, &h->d_prop_own, EN)) ||
-        (rc = dev_alloc(h, &h->d_spair, EN)) || (rc = dev_alloc(h, &h->d_tinfo, (size_t)h->E * h->ntiles)) ||
-        (rc = dev_alloc(h, &h->d_work_ctr, 1)) || (rc = dev_alloc(h, &h->d_stamps, (size_t)8 * 4096)) || (rc = dev_alloc(h, &h->d_pcnt, EL)) ||
+        (rc = dev_alloc(h, &h->d_sp8, EN)) || (rc = dev_alloc(h, &h->d_smask, (size_t)h->E * h->ntiles)) ||
+        (rc = dev_alloc(h, &h->d_tinfo, (size_t)h->E * h->ntiles)) ||
+        (rc = dev_alloc(h, &h->d_work_ctr, 1)) || (rc = dev_alloc(h, &h->d_stamps, (size_t)8 * 4096)) ||
+        (rc = dev_alloc(h, &h->d_plan, (size_t)h->E * h->ntiles * PLAN_CAP)) || (rc = dev_alloc(h, &h->d_plan_n, (size_t)h->E * h->ntiles)) ||
+        (rc = dev_alloc(h, &h->d_accW, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_accS, EN * MAX_SPLIT)) ||
+        (rc = dev_alloc(h, &h->d_occ, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_pcnt, EL)) ||
         (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size())) ||
         (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)2 * h->E)) ||
         (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
@@ -951,9 +1074,9 @@ void aps_destroy(aps_handle *h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
-    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_spair, h->d_tinfo,
-                    h->d_work_ctr, h->d_stamps, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
-                    h->d_nexit, h->d_tiles, h->d_tmp_spair, h->d_tmp_tinfo};
+    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_smask, h->d_tinfo,
+                    h->d_work_ctr, h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
+                    h->d_nexit, h->d_tiles, h->d_tmp_sp8, h->d_tmp_smask, h->d_tmp_tinfo};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1070,12 +1193,20 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_
         HIP_TRY(h, hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    HIP_TRY(h, hipMemsetAsync(h->d_tiles, 0, sizeof(unsigned long long), h->stream));
+    double tiles = 0.0;                                     // source tiles evaluated = sum of the planned list lengths
+    std::vector<uint32_t> pn((size_t)h->E * h->ntiles);
     for (int64_t s = 0; s < nsteps; ++s) {
         int rc;
         HIP_TRY(h, hipEventRecord(h->events[(size_t)(2 * s)], h->stream));
         if ((rc = do_propose(h))) return rc;
         HIP_TRY(h, hipEventRecord(h->events[(size_t)(2 * s + 1)], h->stream));
+        if (pairs && (s == 0 || s == nsteps - 1)) {         // the lists change slowly: sample first and last step
+            HIP_TRY(h, hipMemcpyAsync(pn.data(), h->d_plan_n, pn.size() * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            double t = 0.0;
+            for (uint32_t v : pn) t += v;
+            tiles += t * (nsteps == 1 ? 1.0 : 0.5 * (double)nsteps);
+        }
         if ((rc = do_commit(h))) return rc;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1087,11 +1218,7 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_
     }
     *pair_kernel_ms = total;
     if (launches) *launches = nsteps;
-    if (pairs) {
-        unsigned long long t = 0;
-        HIP_TRY(h, hipMemcpy(&t, h->d_tiles, sizeof(t), hipMemcpyDeviceToHost));
-        *pairs = (double)t * TILE * TILE;
-    }
+    if (pairs) *pairs = tiles * TILE * TILE;
     return APS_OK;
 }
 
@@ -1119,6 +1246,14 @@ int aps_debug_stamps(aps_handle *h, unsigned long long *out, int64_t nwords) {
     if (!h || !out) return APS_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->d_stamps, (size_t)std::min<int64_t>(nwords, 8 * 4096) * 8, hipMemcpyDeviceToHost));
+    return APS_OK;
+}
+
+// diagnostic: per-target-tile planned list lengths of ensemble 0
+int aps_debug_plan_n(aps_handle *h, uint32_t *out, int64_t n) {
+    if (!h || !out) return APS_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->d_plan_n, (size_t)std::min<int64_t>(n, h->ntiles) * 4, hipMemcpyDeviceToHost));
     return APS_OK;
 }
 
@@ -1200,7 +1335,8 @@ int aps_observe(aps_handle *h, int32_t e, int64_t *counts_p, int64_t *counts_m, 
         }
     }
     if (m_field) {
-        int rc = launch_field(h, e, h->d_spair + (size_t)e * h->Npad, h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
+        int rc = launch_field(h, e, h->d_sp8 + (size_t)e * h->Npad, h->d_smask + (size_t)e * h->ntiles,
+                              h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
         if (rc) return rc;
         HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1223,21 +1359,25 @@ int aps_field_from_counts(aps_handle *h, int32_t e, const int64_t *counts_p, con
     if (gs[1] > (long long)4 * h->p.K * L) return fail(h, APS_ERR_ARG, "aps_field_from_counts: more than 4*K*L particles would break the exact-sum bound");
     const size_t nt = (src.size() + TILE - 1) / TILE + 1;
     src.resize(nt * TILE, DEAD_BIT);
-    std::vector<uint2> spair; std::vector<int4> tinfo;
-    derive_sources(src, spair, tinfo);
+    std::vector<uint32_t> sp8; std::vector<unsigned long long> smask; std::vector<int4> tinfo;
+    derive_sources(src, sp8, smask, tinfo);
     if (nt > h->tmp_cap) {
-        if (h->d_tmp_spair) { (void)hipFree(h->d_tmp_spair); (void)hipFree(h->d_tmp_tinfo); h->d_tmp_spair = nullptr; h->d_tmp_tinfo = nullptr; }
+        if (h->d_tmp_sp8) {
+            (void)hipFree(h->d_tmp_sp8); (void)hipFree(h->d_tmp_smask); (void)hipFree(h->d_tmp_tinfo);
+            h->d_tmp_sp8 = nullptr; h->d_tmp_smask = nullptr; h->d_tmp_tinfo = nullptr;
+        }
         int rc;
-        if ((rc = dev_alloc(h, &h->d_tmp_spair, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_tinfo, nt))) return rc;
+        if ((rc = dev_alloc(h, &h->d_tmp_sp8, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_smask, nt)) || (rc = dev_alloc(h, &h->d_tmp_tinfo, nt))) return rc;
         h->tmp_cap = nt;
     }
     long long saved[2];
     HIP_TRY(h, hipMemcpyAsync(saved, h->d_gsum + 2 * e, sizeof(saved), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_spair, spair.data(), spair.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_sp8, sp8.data(), sp8.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_smask, smask.data(), smask.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_tinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gs, sizeof(gs), hipMemcpyHostToDevice, h->stream));
-    int rc = launch_field(h, e, h->d_tmp_spair, h->d_tmp_tinfo, (int)nt, h->d_mfield);
+    int rc = launch_field(h, e, h->d_tmp_sp8, h->d_tmp_smask, h->d_tmp_tinfo, (int)nt, h->d_mfield);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, saved, sizeof(saved), hipMemcpyHostToDevice, h->stream));
