@@ -29,6 +29,19 @@ WORK = dict(N=100_000, L=200_000, K=1, xlim=1.0, sigma=0.005, beta=0.7, rate_act
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
+LDS_CYCLES_PER_64_PAIRS = 5.5  # measured: 4.5 per table gather (2.0 + 2.5 bank conflicts) + 1.0 source broadcast
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 FETCH_SIZE/WRITE_SIZE of this command
+
+
+def measured_traffic_bytes():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py
+    cannot collect PMC itself).  None if the summary is missing."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            d = json.load(fh)["per_dispatch"]["pair_accumulate"]
+        return (d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0
+    except Exception:
+        return None
 
 
 def initial_state(w):
@@ -143,13 +156,17 @@ def main():
         ms, launches, pairs = h.step_timed(reps)
         avg_s = ms / launches * 1e-3
         achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": "pair_propose", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        pairs_per_s = pairs / (ms * 1e-3)
+        lds_peak_pairs = 256 * 2.4e9 / LDS_CYCLES_PER_64_PAIRS * 64      # one LDS pipe per CU
+        roof = {"bound": "hbm", "kernel": "pair_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
                 "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"],
-                "note": "the all-pairs kernel is VALU/LDS-issue bound, not HBM bound (state is 0.4 MB); see valu",
-                "valu": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs / (ms * 1e-3),
-                         "lane_ops_per_pair": 10, "peak_lane_ops_per_s": VALU_LANE_OPS_PER_S,
-                         "frac": pairs / (ms * 1e-3) * 10 / VALU_LANE_OPS_PER_S}}
+                "note": "the contract's HBM figure; this kernel is bound by the LDS table gather (the 0.4 MB state "
+                        "lives in L2), see on_chip",
+                "on_chip": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs_per_s,
+                            "lds_bound_pairs_per_s": lds_peak_pairs, "lds_frac": pairs_per_s / lds_peak_pairs,
+                            "lds_cycles_per_64_pairs": LDS_CYCLES_PER_64_PAIRS,
+                            "valu_lane_ops_per_pair": 10, "valu_frac": pairs_per_s * 10 / VALU_LANE_OPS_PER_S}}
     p, s, b, a = h.get_state()
     assert a.all() and np.bincount(p, minlength=w["L"]).max() <= w["K"]
     h.close()
