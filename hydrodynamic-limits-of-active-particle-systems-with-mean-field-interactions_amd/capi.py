@@ -98,6 +98,8 @@ def load():
         "aps_get_table": (C.c_int, [vp, vp, i32, P(i32), P(i32)]),
         "aps_resort": (C.c_int, [vp]),
         "aps_step_timed": (C.c_int, [vp, i64, P(dbl), P(i64), P(dbl)]),
+        "aps_comm_unique_id": (C.c_int, [vp]),
+        "aps_comm_init": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -200,6 +202,10 @@ class Handle:
     def bind_exchange_buffer(self, dev_ptr, nbytes):
         self._ck(self.lib.aps_bind_exchange_buffer(self._h, C.c_void_p(dev_ptr), int(nbytes)))
 
+    def comm_init(self, id128: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(id128)
+        self._ck(self.lib.aps_comm_init(self._h, C.cast(buf, C.c_void_p)))
+
     def step_timed(self, nsteps):
         ms, n, pairs = C.c_double(), C.c_int64(), C.c_double()
         self._ck(self.lib.aps_step_timed(self._h, int(nsteps), C.byref(ms), C.byref(n), C.byref(pairs)))
@@ -244,3 +250,14 @@ class Handle:
 
 def device_count():
     return load().aps_device_count()
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id (call on one rank, broadcast the bytes to the others).
+    The library dlopens librccl.so.1 lazily; import torch first so that it resolves to the copy torch loaded."""
+    lib = load()
+    buf = (C.c_uint8 * 128)()
+    rc = lib.aps_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != APS_OK:
+        raise ApsError(rc, lib.aps_last_error(None).decode())
+    return bytes(buf)

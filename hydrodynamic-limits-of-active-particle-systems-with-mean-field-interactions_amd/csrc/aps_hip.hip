@@ -22,6 +22,8 @@
 // Compile with -ffp-contract=off: the rate/probability code is a fixed sequence of IEEE operations.
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -730,6 +732,7 @@ struct aps_handle {
     int64_t step = 0;
     std::vector<int64_t> n_set;    // particles uploaded per ensemble
     std::vector<hipEvent_t> events;
+    ncclComm_t comm = nullptr;     // set by aps_comm_init: aps_step then all-gathers the proposals itself
     std::string err;
 };
 
@@ -745,6 +748,34 @@ namespace {
     } while (0)
 
 int fail(aps_handle *h, int code, const std::string &msg) { h->err = msg; return code; }
+
+// RCCL is resolved at run time (no link dependency; reuses the copy the process already loaded, e.g. PyTorch's)
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) {
+            err = "librccl lacks a required symbol"; lib = nullptr; return false;
+        }
+        return true;
+    }
+} g_rccl;
 
 // Weight table (DESIGN.md "Weight table"): unnormalised taps of gaussian_filter1d(truncate=4) with the
 // reflected images folded in, rounded to the grid 2^-q that keeps every possible partial sum exact.
@@ -1073,6 +1104,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
 void aps_destroy(aps_handle *h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_smask, h->d_tinfo,
                     h->d_work_ctr, h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
@@ -1173,11 +1205,18 @@ int aps_commit(aps_handle *h) {
 int aps_step(aps_handle *h, int64_t nsteps) {
     if (!h) return APS_ERR_ARG;
     if (nsteps < 0) return fail(h, APS_ERR_ARG, "aps_step: nsteps < 0");
-    if (h->world != 1) return fail(h, APS_ERR_STATE, "aps_step: sharded handle; use aps_propose / exchange / aps_commit");
+    if (h->world != 1 && !h->comm)
+        return fail(h, APS_ERR_STATE, "aps_step: sharded handle without communicator; call aps_comm_init, or use aps_propose / exchange / aps_commit");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step: upload a state for every ensemble first");
+    const size_t block = (size_t)h->E * (size_t)h->SH;
     for (int64_t s = 0; s < nsteps; ++s) {
         int rc;
-        if ((rc = do_propose(h)) || (rc = do_commit(h))) return rc;
+        if ((rc = do_propose(h))) return rc;
+        if (h->comm) {                                       // one in-place all-gather of 1 byte per particle
+            const ncclResult_t nr = g_rccl.AllGather(h->d_prop + block * (size_t)h->rank, h->d_prop, block, ncclUint8, h->comm, h->stream);
+            if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
+        }
+        if ((rc = do_commit(h))) return rc;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
@@ -1219,6 +1258,29 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_
     *pair_kernel_ms = total;
     if (launches) *launches = nsteps;
     if (pairs) *pairs = tiles * TILE * TILE;
+    return APS_OK;
+}
+
+int aps_comm_unique_id(uint8_t *out128) {
+    if (!out128) return APS_ERR_ARG;
+    if (!g_rccl.load()) { g_create_error = g_rccl.err; return APS_ERR_HIP; }
+    ncclUniqueId id;
+    const ncclResult_t nr = g_rccl.GetUniqueId(&id);
+    if (nr != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(nr); return APS_ERR_HIP; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, &id, 128);
+    return APS_OK;
+}
+
+int aps_comm_init(aps_handle *h, const uint8_t *id128) {
+    if (!h || !id128) return APS_ERR_ARG;
+    if (h->comm) return fail(h, APS_ERR_STATE, "aps_comm_init: communicator already initialised");
+    if (!g_rccl.load()) return fail(h, APS_ERR_HIP, g_rccl.err);
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    const ncclResult_t nr = g_rccl.CommInitRank(&h->comm, h->world, id, h->rank);
+    if (nr != ncclSuccess) { h->comm = nullptr; return fail(h, APS_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(nr)); }
     return APS_OK;
 }
 

@@ -77,7 +77,8 @@ int aps_get_state(aps_handle *h, int32_t ensemble, int32_t *pos, int8_t *sigma, 
  * (ref :294-301).  Arrays are [n] / [n] / [4n] in original order. */
 int aps_pair_accumulate(aps_handle *h, int32_t ensemble, double *S, double *W, int32_t *occ4, int64_t n);
 
-/* replaces the body of the `while t < T` loop (ref :511-516): nsteps synchronous steps of dt. */
+/* replaces the body of the `while t < T` loop (ref :511-516): nsteps synchronous steps of dt.
+ * Sharded handles (world > 1) need aps_comm_init first (or the caller drives propose/exchange/commit). */
 int aps_step(aps_handle *h, int64_t nsteps);
 
 /* The two halves of one step, for callers that exchange proposals between ranks themselves:
@@ -91,6 +92,12 @@ int aps_exchange_buffer(aps_handle *h, void **dev_ptr, int64_t *total_bytes, int
 /* Use caller-owned device memory (>= total_bytes of aps_exchange_buffer) as the proposal buffer, e.g. a
  * torch tensor that torch.distributed all-gathers in place.  NULL returns to the internal buffer. */
 int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes);
+
+/* In-library data path for sharded handles: rank 0 obtains a 128-byte RCCL unique id, the caller broadcasts
+ * it to all ranks (any transport), every rank calls aps_comm_init; afterwards aps_step() runs
+ * propose -> ncclAllGather (in place, 1 byte per particle, on the handle's stream) -> commit per step. */
+int aps_comm_unique_id(uint8_t *out128);
+int aps_comm_init(aps_handle *h, const uint8_t *id128);
 
 /* replaces the observation block (ref :517-536): site histograms and the m-field on all L sites. */
 int aps_observe(aps_handle *h, int32_t ensemble, int64_t *counts_p, int64_t *counts_m, double *m_field);

@@ -351,3 +351,29 @@ def test_hip_engine_over_nccl_world1(capi):
         a.close()
         b.close()
         dist.destroy_process_group()
+
+
+def test_inlibrary_rccl_allgather_world1(capi):
+    """aps_comm_init + aps_step with the library's own ncclAllGather (world size 1: the collective runs in place
+    on one rank) must equal the plain single-GPU stepping."""
+    pytest.importorskip("torch")                          # as in production: torch's librccl is the process's RCCL
+    par = params(L=1500, K=2, sigma=0.02)
+    rng = np.random.default_rng(6)
+    pos, spin = random_state(rng, 1500, 900, 2)
+    a = make_handle(capi, par, 900, seed=3)
+    b = make_handle(capi, par, 900, seed=3)
+    try:
+        a.set_state(pos, spin)
+        b.set_state(pos, spin)
+        ident = capi.comm_unique_id()
+        assert len(ident) == 128
+        a.comm_init(ident)
+        with pytest.raises(capi.ApsError):
+            a.comm_init(ident)                            # second initialisation is refused
+        a.step(40)
+        b.step(40)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert np.array_equal(x, y)
+    finally:
+        a.close()
+        b.close()
