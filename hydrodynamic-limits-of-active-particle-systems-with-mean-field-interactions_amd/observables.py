@@ -1,0 +1,113 @@
+"""Ensemble observables of the reference's sweep drivers, restated (host side, NumPy).
+
+These are the quantities the reference's statistics are judged on; they consume the `out`
+dictionary of `ParticleSystem.run`.  Reference map (file = PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py):
+    velocity_and_window      <- compute_v_eff_and_window      :123-162
+    front_density            <- compute_rho_eff               :165-194
+    blocking_probability     <- compute_blocking_probability  :197-229   (vectorised; the reference loops in Python)
+    mean_magnetisation       <- compute_mean_magnetizatoin    :316-319
+    active_diffusivity       <- compute_D_eff_active          :500-525
+    ensemble_statistics      <- the reduction at the end of sweep_beta_ensemble :97-117
+Pinned by fixture tests/golden/g7_observables.npz (generated from the reference's own functions).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def velocity_and_window(out, L, boundary_xmin=0.99, max_boundary_fraction=0.06, min_window_fraction=0.10):
+    """Centre-of-mass velocity and the averaging window [start, end).
+
+    The window logic reproduces the reference as written: frames with too much mass at the right wall are
+    collected as INDICES, and the reference then bit-inverts a slice of that index array, which is non-zero
+    for every element -- so if any flagged index sits at position >= start of that array the window closes at
+    `start` and is re-opened to the minimum length; otherwise it runs to the end."""
+    times = out["times_obs"]
+    total = out["total_list"]
+    M = total.shape[0]
+    grid = np.linspace(0.0, 1.0, total.shape[1])
+    dx = grid[1] - grid[0]
+    at_wall = total[:, grid >= boundary_xmin].sum(axis=1) * dx
+    mass = total.sum(axis=1) * dx
+    frac_boundary = at_wall / (mass + 1e-12)
+    flagged = np.flatnonzero(frac_boundary >= max_boundary_fraction)
+    start = int(0.65 * M)
+    if flagged.size == 0:
+        end = M
+    else:
+        end = M if flagged[start:].size == 0 else start
+        shortest = max(3, int(min_window_fraction * M))
+        if end - start < shortest:
+            end = min(M, start + shortest)
+    grid = np.linspace(0.0, 1.0, L)
+    com = (total * grid).sum(axis=1) / (total.sum(axis=1) + 1e-12)
+    v_eff = np.gradient(com, times)
+    return float(np.mean(v_eff[start:end])), v_eff, times, start, end, frac_boundary
+
+
+def front_density(out, start, end, window_fraction=0.05):
+    total = np.asarray(out["total_list"])
+    grid = np.linspace(0.0, 1.0, total.shape[1])
+    dx = grid[1] - grid[0]
+    vals = []
+    for t in range(start, end):
+        occupied = np.flatnonzero(total[t] > 0)
+        if occupied.size == 0:
+            continue
+        x_front = grid[occupied[-1]]
+        window = (grid >= x_front - window_fraction) & (grid <= x_front)
+        if window.any():
+            vals.append(total[t][window].sum() * dx / window_fraction)
+    return float(np.mean(vals))
+
+
+def blocking_probability(out, start, end):
+    """Share of the + density whose right neighbour site carries total density >= 1 (reference units)."""
+    total = np.asarray(out["total_list"])[start:end]
+    plus = np.asarray(out["rho_p_list"])[start:end]
+    movers = np.where(plus[:, :-1] > 0, plus[:, :-1], 0.0)
+    attempts = movers.sum()
+    if attempts == 0:
+        return 0.0
+    return float((movers * (total[:, 1:] >= 1.0)).sum() / attempts)
+
+
+def mean_magnetisation(out, start, end):
+    return float(np.mean(np.asarray(out["m_global"], dtype=float)[start:end]))
+
+
+def active_diffusivity(out, dx, start, end):
+    times, frames = out["times_obs"], out["pos_list"]
+    ref, t_ref = frames[start] * dx, times[start]
+    spread, lag = [], []
+    for k in range(start + 1, end):
+        cur = frames[k] * dx
+        n = min(len(ref), len(cur))
+        if n < 2:
+            continue
+        disp = cur[:n] - ref[:n]
+        spread.append(np.sum((disp - np.mean(disp)) ** 2) / (n - 1))
+        lag.append(times[k] - t_ref)
+    return np.polyfit(lag, spread, 1)[0]
+
+
+def run_observables(out, L, dx):
+    """All five per-run observables with the reference's default window parameters."""
+    v, _, _, start, end, _ = velocity_and_window(out, L)
+    return dict(v=v, D=active_diffusivity(out, dx, start, end), m=mean_magnetisation(out, start, end),
+                rho=front_density(out, start, end), block=blocking_probability(out, start, end), window=(start, end))
+
+
+def ensemble_statistics(rows):
+    """Mean / sample standard deviation / standard error over runs, keyed like the reference's savez arrays
+    (..._sweep_beta.py:952-968: means, stds, ses, D_means, D_ses, m_means, m_stds, m_ses, rho_means, rho_ses,
+    block_means, block_ses)."""
+    n = len(rows)
+    col = {k: np.array([r[k] for r in rows], dtype=float) for k in ("v", "D", "m", "rho", "block")}
+    sd = {k: (float(a.std(ddof=1)) if n > 1 else 0.0) for k, a in col.items()}
+    root = np.sqrt(max(1, n))
+    return dict(mean=float(col["v"].mean()), std=sd["v"], se=sd["v"] / root, v_array=col["v"],
+                D_mean=float(col["D"].mean()), D_se=sd["D"] / root,
+                m_mean=float(col["m"].mean()), m_std=sd["m"], m_se=sd["m"] / root,
+                rho_mean=float(col["rho"].mean()), rho_se=sd["rho"] / root,
+                block_mean=float(col["block"].mean()), block_se=sd["block"] / root)

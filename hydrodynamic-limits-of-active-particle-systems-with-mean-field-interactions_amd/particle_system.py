@@ -27,7 +27,7 @@ class ParticleSystem:
                  site_capacity=1, crowding_suppresses_rates=False, k_on=0.1, k_off=0.01,
                  suppress_flip_when_bound=True, k_exit=0,
                  # extensions (all optional, after the reference's keywords)
-                 dt=None, seed=None, device=0, sort_by_site=True):
+                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0):
         self.L = int(L)
         self.xlim = xlim
         self.K = int(site_capacity)
@@ -80,6 +80,7 @@ class ParticleSystem:
         self.seed = seed
         self.device = int(device)
         self.sort_by_site = bool(sort_by_site)
+        self.ensemble = int(ensemble)          # Philox counter word 3 (independent streams under one seed)
         self._handle = None
 
     # ------------------------------------------------------------------ initial conditions (host)
@@ -125,12 +126,14 @@ class ParticleSystem:
                 + max(self.k_on, self.k_off) + self.k_exit)
         return 0.1 / rmax
 
-    def _make_handle(self, n_particles, seed):
+    def _make_handle(self, n_particles, seed, betas=None, ensemble_base=None):
         if self.dt is None:
             self.dt = self.default_dt()
         return capi.Handle(
             L=self.L, K=self.K, periodic=self.periodic, sigma_grid=self._sigma_grid,
-            rate_diffusion=self.rate_diffusion, rate_active=self.rate_active, beta=[float(self.beta)],
+            rate_diffusion=self.rate_diffusion, rate_active=self.rate_active,
+            beta=[float(self.beta)] if betas is None else betas,
+            ensemble_base=self.ensemble if ensemble_base is None else ensemble_base,
             dt=self.dt, seed=seed, n_particles=n_particles, minus_anchor=self.minus_anchor,
             immobilize=self.immobilize_when_anchored, suppress_flip=self.suppress_flip_when_bound,
             crowding=self.crowding_suppresses_rates, k_on=self.k_on, k_off=self.k_off, k_exit=self.k_exit,
@@ -152,60 +155,7 @@ class ParticleSystem:
 
     # ------------------------------------------------------------------ run (ref :450-558)
     def run(self, T=10.0, obs_dt=0.01, record_fft=False, record_var=False):
-        L, dx = self.L, self.dx
-        pos0, sigma0 = self.init_particles()
-        n0 = len(pos0)
-        seed = self.seed if self.seed is not None else int(self.rng.integers(0, 2 ** 63))
-        self.seed_used = seed
-        h = self._handle = self._make_handle(max(n0, 1), seed)
-        try:
-            h.set_state(pos0, sigma0)
-            times_obs = np.arange(0.0, T, obs_dt)
-            M = len(times_obs)
-            pos_list, particle_count_list, bound_list = [None] * M, [None] * M, [None] * M
-            rho_p_list, rho_m_list = np.zeros((M, L)), np.zeros((M, L))
-            total_list, m_local_list = np.zeros((M, L)), np.zeros((M, L))
-            m_global = np.zeros(M)
-            rho_hat_complex = np.zeros((M, L), dtype=complex) if record_fft else None
-            fft_amp_list = np.zeros((M, L)) if record_fft else None
-            var_list = np.zeros(M) if record_var else None
-            done_steps = 0
-            for k in range(M):
-                # smallest step count whose time k*dt reaches the observation time (ref :517)
-                want = int(math.ceil(times_obs[k] / self.dt - 1e-9))
-                if want > done_steps:
-                    h.step(want - done_steps)
-                    done_steps = want
-                pos, sigma, bound, alive = h.get_state()
-                live = alive.astype(bool)
-                p, s = pos[live].astype(np.int64), sigma[live]
-                pos_list[k] = p
-                rho_p, rho_m = self.empirical_densities_from_particles(p, s, L, dx)
-                rho_p_list[k], rho_m_list[k], total_list[k] = rho_p, rho_m, rho_p + rho_m
-                particle_count_list[k] = p.size
-                bound_list[k] = bound[live].astype(bool)
-                m_local_list[k] = h.observe(want_field=True)[2]
-                m_global[k] = np.mean(s) if s.size else np.nan
-                if record_fft:
-                    u = total_list[k]
-                    spec = np.fft.fft(u)
-                    rho_hat_complex[k], fft_amp_list[k] = spec, np.abs(spec)
-                    if record_var:                      # kept only together with the FFT (ref :499-507)
-                        var_list[k] = float(np.var(u))
-                h.resort()
-            ex = h.exits()
-            self.steps_done = done_steps
-        finally:
-            h.close()
-            self._handle = None
-        return {
-            "times_obs": times_obs, "pos_list": pos_list, "rho_p_list": rho_p_list,
-            "rho_m_list": rho_m_list, "total_list": total_list,
-            "particle_count_list": particle_count_list, "bound_list": bound_list,
-            "m_local_list": m_local_list, "m_global": m_global, "rho_hat_complex": rho_hat_complex,
-            "fft_amp_list": fft_amp_list, "var_list": var_list,
-            "exit_times": [float(t) for t in ex[:, 0]], "exit_positions": [int(x) for x in ex[:, 1]],
-        }
+        return run_batched([self], T=T, obs_dt=obs_dt, record_fft=record_fft, record_var=record_var)[0]
 
     # ------------------------------------------------------------------ the one plotting method a driver uses
     def plot_individuals(self, out, show_k_max=6, cmap_name="viridis", xlim=1, fig_size=(10, 6)):
@@ -216,3 +166,84 @@ class ParticleSystem:
         com = (total * grid).sum(axis=1) / (total.sum(axis=1) + 1e-12)
         v_eff = np.gradient(com, out["times_obs"])
         return np.mean(v_eff[int(len(v_eff) * 0.6):])
+
+
+_SHAPE_ATTRS = ("L", "xlim", "K", "rate_diffusion", "rate_active", "k_on", "k_off", "k_exit", "periodic",
+                "local_kernel_sigma", "minus_anchor", "immobilize_when_anchored", "suppress_flip_when_bound",
+                "crowding_suppresses_rates")
+
+
+def run_batched(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var=False):
+    """`run()` of several ParticleSystem objects at once: they may differ in beta, rng / initial condition and
+    particle number but share every other parameter, and are stepped together as independent ensembles of ONE
+    GPU handle (BASELINE config 4; the reference loops over them serially, ..._sweep_beta.py:75-95).
+    Returns the list of result dictionaries (reference :542-557), one per system, in order.
+
+    Ensemble e uses Philox counter word 3 = systems[0].ensemble + e under the common key `seed` of the first
+    system (drawn from its rng after the initial conditions unless given), so a batched run equals separate
+    runs with `ParticleSystem(..., seed=seed, ensemble=e)`."""
+    first = systems[0]
+    for ps in systems[1:]:
+        for k in _SHAPE_ATTRS:
+            if getattr(ps, k) != getattr(first, k):
+                raise ValueError(f"run_batched: systems differ in {k}")
+        if not np.array_equal(ps.is_anchor_site, first.is_anchor_site):
+            raise ValueError("run_batched: systems differ in anchor sites")
+    L, dx = first.L, first.dx
+    inits = [ps.init_particles() for ps in systems]
+    seed = first.seed if first.seed is not None else int(first.rng.integers(0, 2 ** 63))
+    if first.dt is None:
+        first.dt = min(ps.default_dt() for ps in systems)
+    for ps in systems:
+        ps.dt, ps.seed_used = first.dt, seed
+    dt = first.dt
+    cap = max(1, max(len(p) for p, _ in inits))
+    h = first._make_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
+    E = len(systems)
+    try:
+        for e, (pos0, sigma0) in enumerate(inits):
+            h.set_state(pos0, sigma0, ensemble=e)
+        times_obs = np.arange(0.0, T, obs_dt)
+        M = len(times_obs)
+        recs = [dict(pos=[None] * M, count=[None] * M, bound=[None] * M, rho_p=np.zeros((M, L)), rho_m=np.zeros((M, L)),
+                     total=np.zeros((M, L)), m_loc=np.zeros((M, L)), m_glob=np.zeros(M),
+                     hat=np.zeros((M, L), dtype=complex) if record_fft else None,
+                     amp=np.zeros((M, L)) if record_fft else None, var=np.zeros(M) if record_var else None)
+                for _ in range(E)]
+        done_steps = 0
+        for k in range(M):
+            # smallest step count whose time reaches the observation time (ref :517)
+            want = int(math.ceil(times_obs[k] / dt - 1e-9))
+            if want > done_steps:
+                h.step(want - done_steps)
+                done_steps = want
+            for e, rec in enumerate(recs):
+                pos, sigma, bound, alive = h.get_state(ensemble=e)
+                live = alive.astype(bool)
+                p, sg = pos[live].astype(np.int64), sigma[live]
+                rec["pos"][k] = p
+                rho_p, rho_m = ParticleSystem.empirical_densities_from_particles(p, sg, L, dx)
+                rec["rho_p"][k], rec["rho_m"][k], rec["total"][k] = rho_p, rho_m, rho_p + rho_m
+                rec["count"][k] = p.size
+                rec["bound"][k] = bound[live].astype(bool)
+                rec["m_loc"][k] = h.observe(ensemble=e, want_field=True)[2]
+                rec["m_glob"][k] = np.mean(sg) if sg.size else np.nan
+                if record_fft:
+                    u = rec["total"][k]
+                    spec = np.fft.fft(u)
+                    rec["hat"][k], rec["amp"][k] = spec, np.abs(spec)
+                    if record_var:                      # kept only together with the FFT (ref :499-507)
+                        rec["var"][k] = float(np.var(u))
+            h.resort()
+        exits = [h.exits(ensemble=e) for e in range(E)]
+        for ps in systems:
+            ps.steps_done = done_steps
+    finally:
+        h.close()
+    return [{
+        "times_obs": times_obs.copy() if E > 1 else times_obs, "pos_list": rec["pos"], "rho_p_list": rec["rho_p"],
+        "rho_m_list": rec["rho_m"], "total_list": rec["total"], "particle_count_list": rec["count"],
+        "bound_list": rec["bound"], "m_local_list": rec["m_loc"], "m_global": rec["m_glob"],
+        "rho_hat_complex": rec["hat"], "fft_amp_list": rec["amp"], "var_list": rec["var"],
+        "exit_times": [float(t) for t in ex[:, 0]], "exit_positions": [int(x) for x in ex[:, 1]],
+    } for rec, ex in zip(recs, exits)]

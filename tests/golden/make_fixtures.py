@@ -384,6 +384,47 @@ def make_g4():
     _save("g4_ensemble_stats.npz", dict(cases=cases, ctor=G4_CTOR, run=G4_RUN, stride=10), arrays)
 
 
+# --------------------------------------------------------------------------------------- g7
+def make_g7():
+    """Inputs (small reference runs) and outputs of the sweep driver's observable functions
+    (..._sweep_beta.py:123-229, :316-319, :500-525) -- pins package file observables.py."""
+    obs = _load_driver_observables()
+    arrays, cases = {}, []
+    specs = [
+        dict(tag="k1_drift", seed=71, ctor=dict(L=120, xlim=1.0, rate_diffusion=0.05, rate_active=2.0, beta=0.6, init="fixed",
+             N=50, scale_rates=False, local_kernel_sigma=0.02, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0),
+             run=dict(T=6.0, obs_dt=0.1)),
+        dict(tag="k2_ordered", seed=72, ctor=dict(L=100, xlim=1.0, rate_diffusion=0.2, rate_active=1.0, beta=2.5, init="fixed",
+             N=90, scale_rates=False, local_kernel_sigma=0.05, site_capacity=2, k_on=0.0, k_off=0.0, k_exit=0.0),
+             run=dict(T=5.0, obs_dt=0.125)),
+        dict(tag="k1_wall_pileup", seed=73, ctor=dict(L=80, xlim=1.0, rate_diffusion=0.0, rate_active=6.0, beta=0.2, init="fixed",
+             N=40, scale_rates=False, local_kernel_sigma=0.0, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0),
+             run=dict(T=8.0, obs_dt=0.1)),
+    ]
+    for c_idx, sp in enumerate(specs):
+        ps = ref_particle.ParticleSystem(rng=np.random.default_rng(sp["seed"]), **sp["ctor"])
+        out = ps.run(**sp["run"])
+        mean_v, v_ts, times, si, ei, frac_b = obs["compute_v_eff_and_window"](
+            out, ps, boundary_xmin=0.99, max_buondary_fraction=0.06, min_window_fraction=0.10)
+        res = dict(mean_v=mean_v, si=int(si), ei=int(ei),
+                   D=float(obs["compute_D_eff_active"](out, ps, start_idx=si, end_idx=ei)),
+                   m=float(obs["compute_mean_magnetizatoin"](out, si, ei)),
+                   rho=float(obs["compute_rho_eff"](out, si, ei)),
+                   blk=float(obs["compute_blocking_probability"](out, si, ei)))
+        pre = f"c{c_idx}_"
+        arrays[pre + "times_obs"] = out["times_obs"]
+        arrays[pre + "total_list"] = out["total_list"]
+        arrays[pre + "rho_p_list"] = out["rho_p_list"]
+        arrays[pre + "m_global"] = out["m_global"]
+        arrays[pre + "pos_cat"] = np.concatenate(out["pos_list"]).astype(np.int64)
+        arrays[pre + "pos_len"] = np.array([len(p) for p in out["pos_list"]], dtype=np.int64)
+        arrays[pre + "v_ts"] = v_ts
+        arrays[pre + "frac_boundary"] = frac_b
+        cases.append(dict(tag=sp["tag"], L=sp["ctor"]["L"], dx=ps.dx, **res))
+        print("  g7", sp["tag"], res)
+    _save("g7_observables.npz", dict(cases=cases), arrays)
+
+
 # --------------------------------------------------------------------------------------- g6
 def make_g6():
     import IMEX_PDE_solver_class as ref_pde

@@ -100,3 +100,32 @@ def test_compute_local_m_field_method_matches_reference_fixture(golden):
         assert m.shape == (c["L"],) and np.max(np.abs(m - g[f"c{idx}_m"])) <= 2e-11, c
         n += 1
     assert n >= 20
+
+
+def test_batched_beta_sweep_equals_separate_runs():
+    """BASELINE config 4 shape: (beta, run) pairs stepped together in one handle give exactly the results of
+    separate ParticleSystem runs with the same seed and ensemble index; the sweep statistics use observables.py."""
+    import importlib
+    from PARTICLE_solver_CLASS import ParticleSystem
+    ens = importlib.import_module("hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd.ensemble")
+    ps_kwargs = dict(L=300, xlim=1.0, rate_diffusion=0.05, rate_active=3.0, init="fixed", N=120, scale_rates=False,
+                     local_kernel_sigma=0.02, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0, dt=0.02, seed=4242)
+    run_kwargs = dict(T=4.0, obs_dt=0.1)
+    betas, n_runs = [0.0, 1.0, 2.5], 2
+    seeds = [[100 + 10 * b + r for r in range(n_runs)] for b in range(len(betas))]
+    res = ens.sweep_over_betas(betas, n_runs, ps_kwargs=ps_kwargs, run_kwargs=run_kwargs, rng_seeds=seeds, keep_outputs=True)
+    assert set(res) >= {"beta_values", "means", "stds", "ses", "D_means", "D_ses", "m_means", "m_stds", "m_ses",
+                        "rho_means", "rho_ses", "block_means", "block_ses"}
+    assert res["means"].shape == (3,) and np.all(np.isfinite(res["D_means"]))
+    e = 0
+    for bi, beta in enumerate(betas):
+        for r in range(n_runs):
+            solo = ParticleSystem(beta=beta, rng=np.random.default_rng(seeds[bi][r]), ensemble=e, **ps_kwargs)
+            out = solo.run(**run_kwargs)
+            got = res["outs"][e]
+            assert all(np.array_equal(a, b) for a, b in zip(out["pos_list"], got["pos_list"])), (beta, r)
+            assert np.array_equal(out["m_global"], got["m_global"])
+            assert np.array_equal(out["m_local_list"], got["m_local_list"])
+            e += 1
+    # ordered phase at beta = 2.5 vs disordered at 0
+    assert abs(res["m_means"][2]) > abs(res["m_means"][0])
