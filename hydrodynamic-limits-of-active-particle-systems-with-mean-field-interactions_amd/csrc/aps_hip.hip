@@ -206,18 +206,22 @@ __device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const 
 
 // Which loop variant (or none: -1) does the block (targets in [tlo,thi]) x (source tile info sb) need?
 // R = reach of the table in sites (>= 1 so that the occupancy of neighbouring sites is always seen).
+// `margin` (sites) makes the answer conservative for states whose tile bounds moved by up to margin/2 each
+// since the tile infos were taken (stale-tolerant plans): inclusion tests widen, the FAST test narrows.
 template <int BC>
-__device__ __forceinline__ int tile_variant(int tlo, int thi, const int4 sb, int R, int Rtab, int L, bool allow_fast) {
+__device__ __forceinline__ int tile_variant(int tlo, int thi, const int4 sb, int R, int Rtab, int L, bool allow_fast,
+                                            int margin = 0) {
     if (sb.w <= 0) return -1;                                // no live particle in the tile
     const int slo = sb.x, shi = sb.y;
     if (BC == 0) {
-        const bool direct = (slo <= thi + R) && (shi >= tlo - R);
-        const bool mirror = (tlo + slo + 1 <= R) || (2 * L - 1 - thi - shi <= R);
+        const int Rm = R + margin;
+        const bool direct = (slo <= thi + Rm) && (shi >= tlo - Rm);
+        const bool mirror = (tlo + slo + 1 <= Rm) || (2 * L - 1 - thi - shi <= Rm);
         if (mirror) return V_MIRROR;
         if (!direct) return -1;
         const int far = max(thi - slo, shi - tlo);           // largest |p_i - p_j| in the block
         const int gap = slo > thi ? slo - thi : (tlo > shi ? tlo - shi : 0);
-        return (allow_fast && far <= Rtab && gap >= 2 && sb.z == 0) ? V_FAST : V_GENERIC;
+        return (allow_fast && far + margin <= Rtab && gap - margin >= 2 && sb.z == 0) ? V_FAST : V_GENERIC;
     }
     const int lo = slo - thi, hi = shi - tlo;                // range of p_j - p_i
     const bool direct = (hi - lo >= L) || (lo <= R && hi >= -R) || (lo - L <= R && hi - L >= -R) ||
@@ -373,7 +377,7 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
 // plan<BC>: one wave per target tile lists the source tiles that can matter (tile index | loop variant << 28)
 // into plan[e][t][0..PLAN_CAP) and their number into plan_n[e][t] (a count > PLAN_CAP means "scan in-kernel").
 // Correct for any particle order; short lists when the slots are site-sorted.
-struct PlanArgs { int L, tlen, ntiles, tile_lo, tile_cnt; uint32_t *plan, *plan_n; };
+struct PlanArgs { int L, tlen, ntiles, tile_lo, tile_cnt, margin; uint32_t *plan, *plan_n; };
 
 template <int BC>
 __global__ __launch_bounds__(256) void plan_tiles(const PlanArgs a, const int4 *__restrict__ tinfo_all) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void plan_tiles(const PlanArgs a, const int4 *
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int jt = base + u * 64 + lane;
-                const int var = jt < a.ntiles ? tile_variant<BC>(tb.x, tb.y, info[u], R, Rtab, a.L, tb.z == 0) : -1;
+                const int var = jt < a.ntiles ? tile_variant<BC>(tb.x, tb.y, info[u], R, Rtab, a.L, tb.z == 0, a.margin) : -1;
                 const unsigned long long m = __ballot(var >= 0);
                 if (var >= 0) {
                     const unsigned k = n + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
@@ -720,6 +724,7 @@ struct aps_handle {
     unsigned *d_occ = nullptr;
     int split = 1;
     bool plan_dirty = true;
+    int plan_interval = 1, plan_age = 0;       // steps a plan stays valid (margin = 2 * interval sites)
     bool ctr_dirty = true;
     int num_cu = 256, wgs_per_cu = 1;
     double *d_table = nullptr, *d_beta = nullptr, *d_exit = nullptr, *d_S = nullptr, *d_W = nullptr, *d_mfield = nullptr;
@@ -910,7 +915,9 @@ PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
 }
 
 int launch_plan(aps_handle *h, int first_tile, int tile_cnt) {
-    PlanArgs pa{h->p.L, h->tlen, (int)h->ntiles, first_tile, tile_cnt, h->d_plan, h->d_plan_n};
+    PlanArgs pa{h->p.L, h->tlen, (int)h->ntiles, first_tile, tile_cnt, h->plan_interval > 1 ? 2 * h->plan_interval : 0,
+                h->d_plan, h->d_plan_n};
+    h->plan_age = 0;
     const dim3 grid((unsigned)((tile_cnt + 3) / 4), (unsigned)h->E), block(256);
     if (h->p.periodic) hipLaunchKernelGGL(plan_tiles<1>, grid, block, 0, h->stream, pa, h->d_tinfo);
     else hipLaunchKernelGGL(plan_tiles<0>, grid, block, 0, h->stream, pa, h->d_tinfo);
@@ -1009,9 +1016,11 @@ int do_commit(aps_handle *h) {
     hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
     HIP_TRY(h, hipGetLastError());
     h->step += 1;
-    int rc = launch_plan(h, (int)(h->rank * h->SH / TILE), (int)(h->SH / TILE));   // source-tile lists of the new state
-    if (rc) return rc;
-    h->plan_dirty = false;
+    if (++h->plan_age >= h->plan_interval) {                 // source-tile lists for the following step(s)
+        int rc = launch_plan(h, (int)(h->rank * h->SH / TILE), (int)(h->SH / TILE));
+        if (rc) return rc;
+        h->plan_dirty = false;
+    }
     return APS_OK;
 }
 
@@ -1067,6 +1076,10 @@ int aps_create(const aps_params *p, aps_handle **out) {
     M.k_exit = p->k_exit; M.dt = p->dt; M.seed_lo = (uint32_t)p->seed; M.seed_hi = (uint32_t)(p->seed >> 32);
     M.ens_base = p->ensemble_base;
     build_table(h);
+    // A particle moves at most one site per step, so tile bounds drift by <= 1 per step: when nobody can die
+    // (has-dead flags are then static) or wrap around, a plan with a 16-site margin serves 8 steps.
+    h->plan_interval = (!p->periodic && !(p->k_exit > 0.0)) ? 8 : 1;
+    if (const char *env = std::getenv("APS_PLAN_INTERVAL")) h->plan_interval = std::max(1, std::atoi(env));   // tuning knob
 
     auto die = [&](int code) { g_create_error = h->err; aps_destroy(h); return code; };
     if (hipSetDevice(p->device) != hipSuccess) { h->err = "hipSetDevice failed"; return die(APS_ERR_HIP); }

@@ -377,3 +377,30 @@ def test_inlibrary_rccl_allgather_world1(capi):
     finally:
         a.close()
         b.close()
+
+
+def test_table_too_large_for_lds_uses_global_table(capi):
+    """sigma_g = 6000 -> 24001-entry table (188 KB) does not fit LDS: the kernels gather from the table in
+    global memory instead.  Same bit-exact bars."""
+    par = params(L=60000, K=1, sigma=0.1)
+    rng = np.random.default_rng(31)
+    N = 3000
+    pos, spin = random_state(rng, par.L, N, par.K)
+    orc = so.SyncOracle(par, dt=0.05, seed=9)
+    orc.set_state(pos, spin)
+    h = make_handle(capi, par, N, seed=9)
+    try:
+        tab, q = h.table()
+        assert len(tab) == 24001 and q == orc.q and np.array_equal(tab, orc.table)
+        h.set_state(pos, spin)
+        S, W, occ4 = h.pair_accumulate()
+        S0, W0, occ0 = orc.pair_sums()
+        assert np.array_equal(S, S0) and np.array_equal(W, W0) and np.array_equal(occ4, occ0)
+        h.step(10)
+        orc.run(10)
+        p, sg, bd, al = h.get_state()
+        assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin)
+        m = h.observe()[2]
+        assert np.array_equal(m, orc.field_sites()[2])
+    finally:
+        h.close()
