@@ -116,14 +116,18 @@ struct PairArgs {
     Model m;
     const uint32_t *src;      // [E][Npad] packed state (epilogue reads the target's own word)
     const uint32_t *orig;     // [E][Npad]
-    const long long *gsum;    // [E][2] sum of spins, number alive (global-field mode)
+    const long long *gsum;    // [E][2] sum of spins, number alive (global-field mode) of the current state
+    long long *gsum_next;     // [E][2] accumulator apply() fills for the next state (cleared by propose())
     const double *beta;       // [E]
     const uint8_t *anchor;    // [L] or nullptr
     uint8_t *prop;            // [world][E][SH]
-    uint32_t *pcnt;           // [E][L], zeroed by propose() for the commit that follows
+    uint32_t *pcnt;           // [2][E][L] per-site proposer counters; propose() of step n clears the half of step n+1
     double *accW, *accS;      // [split][E][Npad] per-share partial sums (plain stores; propose() adds the shares)
     unsigned *occ;            // [split][E][Npad] packed neighbour-site occupancies: own | left << 10 | right << 20
     int split;                // shares per target tile
+    uint32_t *plist;          // [E][L][2K] per-site proposer lists (used here only when fuse_claim)
+    int parity;               // which half of pcnt[2][E][L] belongs to this step
+    int fuse_claim;           // single GPU: register the hop proposals right here instead of in claim()
     double *S_out, *W_out;    // optional [E][Npad]
     int *occ4_out;            // optional [E][Npad][4]
     unsigned *work_ctr;       // next (ensemble, target tile) item; reset by apply()
@@ -500,11 +504,12 @@ __global__ __launch_bounds__(NTHREADS) void pair_accumulate(const PairArgs a, co
 __global__ __launch_bounds__(256) void propose(const PairArgs a) {
     const Model &M = a.m;
     const int e = blockIdx.y;
-    {
+    {   // the counters of the NEXT step (other parity) are idle now: clear them
+        uint32_t *other = a.pcnt + ((size_t)(a.parity ^ 1) * a.E + e) * M.L;
         const size_t total = (size_t)M.L, nthreads = (size_t)gridDim.x * blockDim.x;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) a.pcnt[(size_t)e * M.L + i] = 0u;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) other[i] = 0u;
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.work_ctr = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.gsum_next[2 * e] = 0; a.gsum_next[2 * e + 1] = 0; }   // apply() accumulates
     const size_t slot = (size_t)a.tile_lo * TILE + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= (size_t)(a.tile_lo + a.tile_cnt) * TILE) return;
     const size_t o = (size_t)e * a.Npad + slot;
@@ -566,6 +571,16 @@ __global__ __launch_bounds__(256) void propose(const PairArgs a) {
     }
     const int r = (int)(slot / a.SH);
     a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
+    if (a.fuse_claim) {                                       // same as claim(): join the target site's proposer list
+        const int ev = code & 7;
+        if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
+            int s = (ev == EV_LEFT) ? p - 1 : p + 1;
+            if (M.periodic) s = s < 0 ? s + M.L : (s >= M.L ? s - M.L : s);
+            const size_t site = (size_t)e * M.L + s;
+            const uint32_t k = atomicAdd(&a.pcnt[(size_t)a.parity * a.E * M.L + site], 1u);
+            if (k < 2u * M.K) a.plist[site * 2 * M.K + k] = a.orig[o];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -576,7 +591,7 @@ struct CommitArgs {
     uint32_t *pcnt, *plist; long long *gsum;
     double *exit_log; unsigned *n_exit; int exit_cap;
     unsigned *work_ctr;
-    int Npad, SH, E, ntiles;
+    int Npad, SH, E, ntiles, parity;
     double step_as_double;
 };
 
@@ -589,10 +604,6 @@ __device__ inline int hop_target(const Model &M, int p, int ev) {
 __global__ __launch_bounds__(256) void claim(const CommitArgs a) {
     const int e = blockIdx.y;
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot == 0) {
-        a.gsum[2 * e] = 0; a.gsum[2 * e + 1] = 0;            // apply() re-accumulates them
-        if (e == 0) *a.work_ctr = 0u;                         // next pair_propose launch starts at item 0
-    }
     if (slot >= (size_t)a.Npad) return;
     const int r = (int)(slot / a.SH);
     const uint8_t code = a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)];
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(256) void claim(const CommitArgs a) {
     const uint32_t me = a.src[(size_t)e * a.Npad + slot];
     const int s = hop_target(a.m, (int)(me & POS_MASK), ev);
     const size_t site = (size_t)e * a.m.L + s;
-    const uint32_t k = atomicAdd(&a.pcnt[site], 1u);
+    const uint32_t k = atomicAdd(&a.pcnt[(size_t)a.parity * a.E * a.m.L + site], 1u);
     if (k < 2u * a.m.K) a.plist[site * 2 * a.m.K + k] = a.orig[(size_t)e * a.Npad + slot];
 }
 
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
         if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
             const int s = hop_target(a.m, p, ev);
             const size_t site = (size_t)e * a.m.L + s;
-            const uint32_t n = min(a.pcnt[site], 2u * a.m.K);
+            const uint32_t n = min(a.pcnt[(size_t)a.parity * a.E * a.m.L + site], 2u * a.m.K);
             int rank = 0;                                     // proposers to s with a smaller particle index
             for (uint32_t k = 0; k < n; ++k) rank += a.plist[site * 2 * a.m.K + k] < my_orig;
             if (rank < (code >> 3) + 1) { p = s; me = (me & ~POS_MASK) | (uint32_t)s; }
@@ -903,7 +914,10 @@ int upload_ensemble(aps_handle *h, int e, const std::vector<uint32_t> &src, cons
 PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
     PairArgs a{};
     a.m = h->model;
-    a.src = h->d_src; a.orig = h->d_orig; a.gsum = h->d_gsum; a.work_ctr = h->d_work_ctr; a.stamps = h->d_stamps; a.plan_n = h->d_plan_n;
+    a.src = h->d_src; a.orig = h->d_orig; a.work_ctr = h->d_work_ctr;
+    a.parity = (int)(h->step & 1);
+    a.gsum = h->d_gsum + (size_t)a.parity * 2 * h->E; a.gsum_next = h->d_gsum + (size_t)(a.parity ^ 1) * 2 * h->E;
+    a.plist = h->d_plist; a.fuse_claim = (h->world == 1 && write_prop) ? 1 : 0; a.stamps = h->d_stamps; a.plan_n = h->d_plan_n;
     a.accW = h->d_accW; a.accS = h->d_accS; a.occ = h->d_occ; a.split = h->split;
     a.beta = h->d_beta; a.anchor = h->d_anchor; a.prop = h->d_prop; a.pcnt = h->d_pcnt;
     a.S_out = hook ? h->d_S : nullptr; a.W_out = hook ? h->d_W : nullptr; a.occ4_out = hook ? h->d_occ4 : nullptr;
@@ -965,7 +979,8 @@ CommitArgs commit_args(aps_handle *h) {
     CommitArgs c{};
     c.m = h->model; c.src = h->d_src; c.orig = h->d_orig; c.prop = h->d_prop; c.pcnt = h->d_pcnt;
     c.sp8 = h->d_sp8; c.smask = h->d_smask; c.tinfo = h->d_tinfo; c.work_ctr = h->d_work_ctr;
-    c.plist = h->d_plist; c.gsum = h->d_gsum; c.exit_log = h->d_exit;
+    c.parity = (int)(h->step & 1);
+    c.plist = h->d_plist; c.gsum = h->d_gsum + (size_t)(c.parity ^ 1) * 2 * h->E; c.exit_log = h->d_exit;
     c.n_exit = h->d_nexit; c.exit_cap = h->exit_cap; c.Npad = (int)h->Npad; c.SH = (int)h->SH; c.E = h->E;
     c.ntiles = (int)h->ntiles; c.step_as_double = (double)h->step;
     return c;
@@ -992,7 +1007,7 @@ int set_lds_limit(aps_handle *h) {
 
 int launch_field(aps_handle *h, int e, const uint32_t *sp8, const unsigned long long *smask, const int4 *tinfo, int ntiles, double *m_out) {
     FieldArgs f{};
-    f.m = h->model; f.gsum = h->d_gsum; f.m_out = m_out;
+    f.m = h->model; f.gsum = h->d_gsum + (size_t)(h->step & 1) * 2 * h->E; f.m_out = m_out;
     f.tlen = h->tlen; f.ntiles = ntiles; f.e = e;
     const dim3 grid((unsigned)((h->p.L + TILE * WAVES - 1) / (TILE * WAVES))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
@@ -1012,7 +1027,7 @@ int do_propose(aps_handle *h) {
 int do_commit(aps_handle *h) {
     const CommitArgs c = commit_args(h);
     const dim3 grid((unsigned)(h->Npad / 256), (unsigned)h->E), block(256);
-    hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);
+    if (h->world != 1) hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);   // one GPU: propose() registered the hops
     hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
     HIP_TRY(h, hipGetLastError());
     h->step += 1;
@@ -1095,9 +1110,9 @@ int aps_create(const aps_params *p, aps_handle **out) {
         (rc = dev_alloc(h, &h->d_work_ctr, 1)) || (rc = dev_alloc(h, &h->d_stamps, (size_t)8 * 4096)) ||
         (rc = dev_alloc(h, &h->d_plan, (size_t)h->E * h->ntiles * PLAN_CAP)) || (rc = dev_alloc(h, &h->d_plan_n, (size_t)h->E * h->ntiles)) ||
         (rc = dev_alloc(h, &h->d_accW, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_accS, EN * MAX_SPLIT)) ||
-        (rc = dev_alloc(h, &h->d_occ, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_pcnt, EL)) ||
+        (rc = dev_alloc(h, &h->d_occ, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_pcnt, 2 * EL)) ||
         (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size())) ||
-        (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)2 * h->E)) ||
+        (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)4 * h->E)) ||
         (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
         (rc = dev_alloc(h, &h->d_tiles, 1)) || (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))
         return die(rc);
@@ -1149,7 +1164,7 @@ int aps_set_state(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *si
     pack_ensemble(h, pos, sigma, bound, alive, n, src, orig, gsum);
     int rc = upload_ensemble(h, e, src, orig);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gsum, sizeof(gsum), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + (size_t)(h->step & 1) * 2 * h->E + 2 * e, gsum, sizeof(gsum), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_nexit + e, 0, sizeof(unsigned), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_set[(size_t)e] = n;
@@ -1446,16 +1461,17 @@ int aps_field_from_counts(aps_handle *h, int32_t e, const int64_t *counts_p, con
         h->tmp_cap = nt;
     }
     long long saved[2];
-    HIP_TRY(h, hipMemcpyAsync(saved, h->d_gsum + 2 * e, sizeof(saved), hipMemcpyDeviceToHost, h->stream));
+    long long *gcur = h->d_gsum + (size_t)(h->step & 1) * 2 * h->E + 2 * e;
+    HIP_TRY(h, hipMemcpyAsync(saved, gcur, sizeof(saved), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_sp8, sp8.data(), sp8.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_smask, smask.data(), smask.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_tinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, gs, sizeof(gs), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(gcur, gs, sizeof(gs), hipMemcpyHostToDevice, h->stream));
     int rc = launch_field(h, e, h->d_tmp_sp8, h->d_tmp_smask, h->d_tmp_tinfo, (int)nt, h->d_mfield);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_gsum + 2 * e, saved, sizeof(saved), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(gcur, saved, sizeof(saved), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
 }
