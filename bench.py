@@ -26,6 +26,11 @@ PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactio
 
 WORK = dict(N=100_000, L=200_000, K=1, xlim=1.0, sigma=0.005, beta=0.7, rate_active=5.0, rate_diffusion=0.02,
             dt=0.0125, seed=0)
+# other BASELINE configurations, for the record only (never the default bench line): --workload config4 / config5
+EXTRA = {
+    "config4": dict(WORK, N=50_000, L=100_000, betas=[3.0 * i / 15 for i in range(16)]),     # 16 beta ensembles, one GPU
+    "config5": dict(WORK, N=1_000_000, L=2_000_000),                                          # f64 here (no f32 path)
+}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
@@ -53,7 +58,7 @@ def initial_state(w):
 
 def make_handle(capi, w, device=0, rank=0, world=1):
     return capi.Handle(L=w["L"], K=w["K"], periodic=False, sigma_grid=w["sigma"] / (w["xlim"] / w["L"]),
-                       rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"], beta=[w["beta"]],
+                       rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"], beta=w.get("betas", [w["beta"]]),
                        dt=w["dt"], seed=w["seed"], n_particles=w["N"], device=device, rank=rank, world=world)
 
 
@@ -108,8 +113,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2", choices=["config2"] + sorted(EXTRA))
     args = ap.parse_args()
-    w = dict(WORK)
+    w = dict(WORK) if args.workload == "config2" else dict(EXTRA[args.workload])
+    n_ens = len(w.get("betas", [0]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,7 +172,8 @@ def main():
         comm_path = path
     else:
         h = make_handle(capi, w)
-        h.set_state(pos, spin)
+        for e in range(n_ens):
+            h.set_state(pos, spin, ensemble=e)
         h.step(args.warmup)                       # aps_step synchronises its stream before returning
         t0 = time.perf_counter()
         h.step(args.steps)
@@ -174,12 +182,12 @@ def main():
         reps = max(10, min(args.steps, 50))
         ms, launches, pairs = h.step_timed(reps)
         avg_s = ms / launches * 1e-3
-        achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] / avg_s / 1e9
+        achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens / avg_s / 1e9
         pairs_per_s = pairs / (ms * 1e-3)
         lds_peak_pairs = 256 * 2.4e9 / LDS_CYCLES_PER_64_PAIRS * 64      # one LDS pipe per CU
         roof = {"bound": "hbm", "kernel": "pair_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
-                "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"],
+                "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens,
                 "note": "the contract's HBM figure; this kernel is bound by the LDS table gather (the 0.4 MB state "
                         "lives in L2), see on_chip",
                 "on_chip": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs_per_s,
@@ -192,17 +200,18 @@ def main():
     if rank != 0:
         return
     out = {
-        "metric": "particle-steps/sec at N=1e5", "value": w["N"] * args.steps / elapsed, "unit": "particle-steps/s",
+        "metric": "particle-steps/sec at N=1e5", "value": w["N"] * n_ens * args.steps / elapsed, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
-                               "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on",
+        "config": {"workload": ("BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
+                                "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on") if args.workload == "config2"
+                               else f"BASELINE {args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma=0.005, dt=0.0125",
                    "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"
                                + (f" ({comm_path})" if world > 1 else "")},
     }
     if roof:
         out["roofline"] = roof
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.workload == "config2":
         out["cpu_baseline"] = cpu_baseline(w)
         out["cpu_reference_loop"] = cpu_reference_loop(w)
     print(json.dumps(out))

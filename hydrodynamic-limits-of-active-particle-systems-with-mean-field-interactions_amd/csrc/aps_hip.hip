@@ -130,7 +130,6 @@ struct PairArgs {
     int fuse_claim;           // single GPU: register the hop proposals right here instead of in claim()
     double *S_out, *W_out;    // optional [E][Npad]
     int *occ4_out;            // optional [E][Npad][4]
-    unsigned *work_ctr;       // next (ensemble, target tile) item; reset by apply()
     unsigned long long *stamps;   // diagnostic build only (APS_STAMPS): per-workgroup phase cycle totals
     const uint32_t *plan_n;   // [E][ntiles] number of planned source tiles (> PLAN_CAP: overflow)
     int tlen, Npad, SH, E, ntiles, tile_lo, tile_cnt;
@@ -159,6 +158,9 @@ __device__ __forceinline__ double table_at(const double *__restrict__ table_g, u
 #ifndef APS_G
 #define APS_G 16
 #endif
+#ifndef APS_TA_EVERY
+#define APS_TA_EVERY 0                        // 0: all table gathers from LDS
+#endif
 constexpr int G = APS_G;                      // sources per group = G/4 broadcast ds_read_b128
 constexpr int NACC = 4;                       // independent accumulator chains (sums are exact: order-free)
 
@@ -179,7 +181,12 @@ __device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const 
 #if defined(APS_ABL_NOLDS)          /* timing-only ablations (wrong results): no table read at all */
             wt = (double)sad3(pi8, p8[k], tbase);
 #else
-            wt = table_at<TAB_LDS>(table_g, sad3(pi8, p8[k], tbase));
+            // every APS_TA_EVERY-th gather goes through the vector L1 path (same table in global memory): the
+            // texture-addresser pipe works in parallel with the LDS pipe, which is the busier one
+            if (TAB_LDS && APS_TA_EVERY > 0 && (k % (APS_TA_EVERY > 0 ? APS_TA_EVERY : 1)) == 0)
+                wt = table_at<false>(table_g, sad3(pi8, p8[k], 0u));
+            else
+                wt = table_at<TAB_LDS>(table_g, sad3(pi8, p8[k], tbase));
 #endif
         } else {
             const uint32_t d8 = sad3(pi8, p8[k], 0u);
@@ -428,7 +435,6 @@ __global__ __launch_bounds__(256) void plan_tiles(const PlanArgs a, const int4 *
 // compiler can prove the wave-uniform reads are never clobbered and emits scalar loads.
 template <int BC, bool TAB_LDS>
 __global__ __launch_bounds__(NTHREADS) void pair_accumulate(const PairArgs a, const uint32_t *__restrict__ sp8_all,
-                                                           const uint64_t *__restrict__ smask_all,
                                                            const int4 *__restrict__ tinfo_all,
                                                            const double *__restrict__ table_g,
                                                            const uint32_t *__restrict__ plan_all,
@@ -587,10 +593,9 @@ __global__ __launch_bounds__(256) void propose(const PairArgs a) {
 struct CommitArgs {
     Model m;
     uint32_t *src; const uint32_t *orig; const uint8_t *prop;
-    uint32_t *sp8; unsigned long long *smask; int4 *tinfo;
+    uint32_t *sp8; int4 *tinfo;
     uint32_t *pcnt, *plist; long long *gsum;
     double *exit_log; unsigned *n_exit; int exit_cap;
-    unsigned *work_ctr;
     int Npad, SH, E, ntiles, parity;
     double step_as_double;
 };
@@ -649,7 +654,6 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     // pre-decoded source pair for the next all-pairs pass, per-tile (= per-wave) info, global spin sums
     const bool live = !(me & DEAD_BIT);
     if (ev != EV_NONE) a.sp8[(size_t)e * a.Npad + slot] = live ? (((uint32_t)p << 3) | ((me & SPIN_BIT) ? 1u : 0u)) : DEAD_P8;
-    const unsigned long long plus_mask = __ballot(live && (me & SPIN_BIT));
     int lo = live ? p : 0x7fffffff, hi = live ? p : -1;
     int ssum = live ? ((me & SPIN_BIT) ? 1 : -1) : 0, cnt = live ? 1 : 0;
 #pragma unroll
@@ -659,7 +663,6 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     }
     if ((threadIdx.x & 63) == 0) {
         a.tinfo[(size_t)e * a.ntiles + slot / TILE] = make_int4(lo, hi, cnt < TILE ? 1 : 0, cnt);
-        a.smask[(size_t)e * a.ntiles + slot / TILE] = plus_mask;
         if (a.m.field_mode == 0 && cnt) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e]), (unsigned long long)(long long)ssum);
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e + 1]), (unsigned long long)cnt);
@@ -675,7 +678,6 @@ struct FieldArgs {
 
 template <int BC, bool TAB_LDS>
 __global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const uint32_t *__restrict__ sp8,
-                                                       const uint64_t *__restrict__ smask,
                                                        const int4 *__restrict__ tinfo,
                                                        const double *__restrict__ table_g) {
     extern __shared__ double lds[];
@@ -726,9 +728,7 @@ struct aps_handle {
     uint32_t *d_src = nullptr, *d_orig = nullptr, *d_pcnt = nullptr, *d_plist = nullptr;
     uint8_t *d_prop = nullptr, *d_prop_own = nullptr, *d_anchor = nullptr;
     uint32_t *d_sp8 = nullptr;
-    unsigned long long *d_smask = nullptr;
     int4 *d_tinfo = nullptr;
-    unsigned *d_work_ctr = nullptr;
     unsigned long long *d_stamps = nullptr;
     uint32_t *d_plan = nullptr, *d_plan_n = nullptr;
     double *d_accW = nullptr, *d_accS = nullptr;
@@ -736,14 +736,12 @@ struct aps_handle {
     int split = 1;
     bool plan_dirty = true;
     int plan_interval = 1, plan_age = 0;       // steps a plan stays valid (margin = 2 * interval sites)
-    bool ctr_dirty = true;
     int num_cu = 256, wgs_per_cu = 1;
     double *d_table = nullptr, *d_beta = nullptr, *d_exit = nullptr, *d_S = nullptr, *d_W = nullptr, *d_mfield = nullptr;
     int *d_occ4 = nullptr;
     long long *d_gsum = nullptr;
     unsigned *d_nexit = nullptr;
-    unsigned long long *d_tiles = nullptr;
-    uint32_t *d_tmp_sp8 = nullptr; unsigned long long *d_tmp_smask = nullptr; int4 *d_tmp_tinfo = nullptr; size_t tmp_cap = 0;
+    uint32_t *d_tmp_sp8 = nullptr; int4 *d_tmp_tinfo = nullptr; size_t tmp_cap = 0;
     int exit_cap = 0;
     int64_t step = 0;
     std::vector<int64_t> n_set;    // particles uploaded per ensemble
@@ -849,19 +847,16 @@ int dev_alloc(aps_handle *h, T **ptr, size_t count) {
     return APS_OK;
 }
 
-// per-tile info, spin masks and pre-decoded source words of a slot array (host mirror of what apply() maintains)
-void derive_sources(const std::vector<uint32_t> &src, std::vector<uint32_t> &sp8, std::vector<unsigned long long> &smask,
-                    std::vector<int4> &tinfo) {
+// per-tile info and pre-decoded source words of a slot array (host mirror of what apply() maintains)
+void derive_sources(const std::vector<uint32_t> &src, std::vector<uint32_t> &sp8, std::vector<int4> &tinfo) {
     const size_t n = src.size(), nt = n / TILE;
     sp8.resize(n);
-    smask.assign(nt, 0ull);
     tinfo.assign(nt, make_int4(0x7fffffff, -1, 1, 0));
     for (size_t s = 0; s < n; ++s) {
         const uint32_t w = src[s];
         const bool live = !(w & DEAD_BIT);
         sp8[s] = live ? (((w & POS_MASK) << 3) | ((w & SPIN_BIT) ? 1u : 0u)) : DEAD_P8;
         if (!live) continue;
-        if (w & SPIN_BIT) smask[s / TILE] |= 1ull << (s % TILE);
         int4 &t = tinfo[s / TILE];
         const int p = (int)(w & POS_MASK);
         t.x = std::min(t.x, p); t.y = std::max(t.y, p); t.w += 1;
@@ -899,12 +894,11 @@ void pack_ensemble(const aps_handle *h, const int32_t *pos, const int8_t *sigma,
 }
 
 int upload_ensemble(aps_handle *h, int e, const std::vector<uint32_t> &src, const std::vector<uint32_t> &orig) {
-    std::vector<uint32_t> sp8; std::vector<unsigned long long> smask; std::vector<int4> tinfo;
-    derive_sources(src, sp8, smask, tinfo);
+    std::vector<uint32_t> sp8; std::vector<int4> tinfo;
+    derive_sources(src, sp8, tinfo);
     HIP_TRY(h, hipMemcpyAsync(h->d_src + (size_t)e * h->Npad, src.data(), src.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_orig + (size_t)e * h->Npad, orig.data(), orig.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_sp8 + (size_t)e * h->Npad, sp8.data(), sp8.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_smask + (size_t)e * h->ntiles, smask.data(), smask.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tinfo + (size_t)e * h->ntiles, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->plan_dirty = true;
@@ -914,7 +908,7 @@ int upload_ensemble(aps_handle *h, int e, const std::vector<uint32_t> &src, cons
 PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
     PairArgs a{};
     a.m = h->model;
-    a.src = h->d_src; a.orig = h->d_orig; a.work_ctr = h->d_work_ctr;
+    a.src = h->d_src; a.orig = h->d_orig;
     a.parity = (int)(h->step & 1);
     a.gsum = h->d_gsum + (size_t)a.parity * 2 * h->E; a.gsum_next = h->d_gsum + (size_t)(a.parity ^ 1) * 2 * h->E;
     a.plist = h->d_plist; a.fuse_claim = (h->world == 1 && write_prop) ? 1 : 0; a.stamps = h->d_stamps; a.plan_n = h->d_plan_n;
@@ -948,8 +942,6 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
         if (rc) return rc;
         h->plan_dirty = (first_tile != shard_lo || tile_cnt != shard_cnt);
     }
-    if (h->ctr_dirty) HIP_TRY(h, hipMemsetAsync(h->d_work_ctr, 0, sizeof(unsigned), h->stream));
-    h->ctr_dirty = false;                                   // propose() resets the counter after use
     // Shares per target tile.  Items are dealt to the resident waves round-robin, so pick the split whose
     // item count fills whole rounds best (smallest idle fraction in the last round), with >= 2 rounds if possible.
     const unsigned slots = (unsigned)(h->num_cu * h->wgs_per_cu * WAVES);
@@ -965,7 +957,7 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
     const unsigned items = (unsigned)tile_cnt * (unsigned)h->E * (unsigned)split;
     const dim3 grid(std::max(1u, std::min((items + WAVES - 1) / WAVES, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_accumulate<BC, TL>), grid, block, lds, h->stream, b, h->d_sp8, reinterpret_cast<const uint64_t *>(h->d_smask), h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_accumulate<BC, TL>), grid, block, lds, h->stream, b, h->d_sp8, h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
@@ -978,7 +970,7 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
 CommitArgs commit_args(aps_handle *h) {
     CommitArgs c{};
     c.m = h->model; c.src = h->d_src; c.orig = h->d_orig; c.prop = h->d_prop; c.pcnt = h->d_pcnt;
-    c.sp8 = h->d_sp8; c.smask = h->d_smask; c.tinfo = h->d_tinfo; c.work_ctr = h->d_work_ctr;
+    c.sp8 = h->d_sp8; c.tinfo = h->d_tinfo;
     c.parity = (int)(h->step & 1);
     c.plist = h->d_plist; c.gsum = h->d_gsum + (size_t)(c.parity ^ 1) * 2 * h->E; c.exit_log = h->d_exit;
     c.n_exit = h->d_nexit; c.exit_cap = h->exit_cap; c.Npad = (int)h->Npad; c.SH = (int)h->SH; c.E = h->E;
@@ -1005,13 +997,13 @@ int set_lds_limit(aps_handle *h) {
     return APS_OK;
 }
 
-int launch_field(aps_handle *h, int e, const uint32_t *sp8, const unsigned long long *smask, const int4 *tinfo, int ntiles, double *m_out) {
+int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, int ntiles, double *m_out) {
     FieldArgs f{};
     f.m = h->model; f.gsum = h->d_gsum + (size_t)(h->step & 1) * 2 * h->E; f.m_out = m_out;
     f.tlen = h->tlen; f.ntiles = ntiles; f.e = e;
     const dim3 grid((unsigned)((h->p.L + TILE * WAVES - 1) / (TILE * WAVES))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, sp8, reinterpret_cast<const uint64_t *>(smask), tinfo, h->d_table)
+#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((field_sites<BC, TL>), grid, block, lds, h->stream, f, sp8, tinfo, h->d_table)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
@@ -1105,16 +1097,16 @@ int aps_create(const aps_params *p, aps_handle **out) {
     const size_t EN = (size_t)h->E * (size_t)h->Npad, EL = (size_t)h->E * (size_t)p->L;
     h->exit_cap = (int)std::max<int64_t>(h->N, 1);
     if ((rc = dev_alloc(h, &h->d_src, EN)) || (rc = dev_alloc(h, &h->d_orig, EN)) || (rc = dev_alloc(h, &h->d_prop_own, EN)) ||
-        (rc = dev_alloc(h, &h->d_sp8, EN)) || (rc = dev_alloc(h, &h->d_smask, (size_t)h->E * h->ntiles)) ||
+        (rc = dev_alloc(h, &h->d_sp8, EN)) ||
         (rc = dev_alloc(h, &h->d_tinfo, (size_t)h->E * h->ntiles)) ||
-        (rc = dev_alloc(h, &h->d_work_ctr, 1)) || (rc = dev_alloc(h, &h->d_stamps, (size_t)8 * 4096)) ||
+        (rc = dev_alloc(h, &h->d_stamps, (size_t)8 * 4096)) ||
         (rc = dev_alloc(h, &h->d_plan, (size_t)h->E * h->ntiles * PLAN_CAP)) || (rc = dev_alloc(h, &h->d_plan_n, (size_t)h->E * h->ntiles)) ||
         (rc = dev_alloc(h, &h->d_accW, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_accS, EN * MAX_SPLIT)) ||
         (rc = dev_alloc(h, &h->d_occ, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_pcnt, 2 * EL)) ||
         (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size())) ||
         (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)4 * h->E)) ||
         (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
-        (rc = dev_alloc(h, &h->d_tiles, 1)) || (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))
+        (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))
         return die(rc);
     h->d_prop = h->d_prop_own;
     if (p->anchor_mask) {
@@ -1134,9 +1126,9 @@ void aps_destroy(aps_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
-    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_smask, h->d_tinfo,
-                    h->d_work_ctr, h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
-                    h->d_nexit, h->d_tiles, h->d_tmp_sp8, h->d_tmp_smask, h->d_tmp_tinfo};
+    void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
+                    h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
+                    h->d_nexit, h->d_tmp_sp8, h->d_tmp_tinfo};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1425,8 +1417,7 @@ int aps_observe(aps_handle *h, int32_t e, int64_t *counts_p, int64_t *counts_m, 
         }
     }
     if (m_field) {
-        int rc = launch_field(h, e, h->d_sp8 + (size_t)e * h->Npad, h->d_smask + (size_t)e * h->ntiles,
-                              h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
+        int rc = launch_field(h, e, h->d_sp8 + (size_t)e * h->Npad, h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield);
         if (rc) return rc;
         HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1449,26 +1440,25 @@ int aps_field_from_counts(aps_handle *h, int32_t e, const int64_t *counts_p, con
     if (gs[1] > (long long)4 * h->p.K * L) return fail(h, APS_ERR_ARG, "aps_field_from_counts: more than 4*K*L particles would break the exact-sum bound");
     const size_t nt = (src.size() + TILE - 1) / TILE + 1;
     src.resize(nt * TILE, DEAD_BIT);
-    std::vector<uint32_t> sp8; std::vector<unsigned long long> smask; std::vector<int4> tinfo;
-    derive_sources(src, sp8, smask, tinfo);
+    std::vector<uint32_t> sp8; std::vector<int4> tinfo;
+    derive_sources(src, sp8, tinfo);
     if (nt > h->tmp_cap) {
         if (h->d_tmp_sp8) {
-            (void)hipFree(h->d_tmp_sp8); (void)hipFree(h->d_tmp_smask); (void)hipFree(h->d_tmp_tinfo);
-            h->d_tmp_sp8 = nullptr; h->d_tmp_smask = nullptr; h->d_tmp_tinfo = nullptr;
+            (void)hipFree(h->d_tmp_sp8); (void)hipFree(h->d_tmp_tinfo);
+            h->d_tmp_sp8 = nullptr; h->d_tmp_tinfo = nullptr;
         }
         int rc;
-        if ((rc = dev_alloc(h, &h->d_tmp_sp8, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_smask, nt)) || (rc = dev_alloc(h, &h->d_tmp_tinfo, nt))) return rc;
+        if ((rc = dev_alloc(h, &h->d_tmp_sp8, nt * TILE)) || (rc = dev_alloc(h, &h->d_tmp_tinfo, nt))) return rc;
         h->tmp_cap = nt;
     }
     long long saved[2];
     long long *gcur = h->d_gsum + (size_t)(h->step & 1) * 2 * h->E + 2 * e;
     HIP_TRY(h, hipMemcpyAsync(saved, gcur, sizeof(saved), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_sp8, sp8.data(), sp8.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_smask, smask.data(), smask.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_tinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(gcur, gs, sizeof(gs), hipMemcpyHostToDevice, h->stream));
-    int rc = launch_field(h, e, h->d_tmp_sp8, h->d_tmp_smask, h->d_tmp_tinfo, (int)nt, h->d_mfield);
+    int rc = launch_field(h, e, h->d_tmp_sp8, h->d_tmp_tinfo, (int)nt, h->d_mfield);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(m_field, h->d_mfield, (size_t)L * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(gcur, saved, sizeof(saved), hipMemcpyHostToDevice, h->stream));
