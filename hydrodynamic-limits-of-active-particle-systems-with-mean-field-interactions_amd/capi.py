@@ -98,6 +98,7 @@ def load():
         "aps_get_table": (C.c_int, [vp, vp, i32, P(i32), P(i32)]),
         "aps_resort": (C.c_int, [vp]),
         "aps_step_timed": (C.c_int, [vp, i64, P(dbl), P(i64), P(dbl)]),
+        "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
     }
@@ -224,6 +225,19 @@ class Handle:
         m = np.zeros(self.L)
         self._ck(self.lib.aps_field_from_counts(self._h, ensemble, _ptr(cp), _ptr(cm), _ptr(m)))
         return m
+
+    def rates_from_field(self, pos, sigma, bound, m_field, counts_p, counts_m, ensemble=0):
+        """dict of the nine rate vectors of step_gillespie's rate section for caller-supplied arrays."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        sigma = np.ascontiguousarray(sigma, dtype=np.int8)
+        bound = np.ascontiguousarray(bound, dtype=np.uint8)
+        m_field = np.ascontiguousarray(m_field, dtype=np.float64)
+        cp = np.ascontiguousarray(counts_p, dtype=np.int64)
+        cm = np.ascontiguousarray(counts_m, dtype=np.int64)
+        out = np.zeros((9, len(pos)))
+        self._ck(self.lib.aps_rates_from_field(self._h, ensemble, _ptr(pos), _ptr(sigma), _ptr(bound), len(pos), _ptr(m_field),
+                                               _ptr(cp), _ptr(cm), _ptr(out)))
+        return dict(zip(("diff", "act", "flip", "bind", "unbind", "exit", "left", "right", "total"), out))
 
     def time(self):
         t, k = C.c_double(), C.c_int64()

@@ -670,6 +670,28 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     }
 }
 
+// Rate vectors of step_gillespie (ref :254-352) for caller-supplied particles, m-field and site histograms:
+// out[c][i], c = diff, act, flip, bind, unbind, exit, left, right, total.
+struct RatesArgs {
+    Model m; double beta; const int32_t *pos; const int8_t *sigma; const uint8_t *bound; const double *m_field;
+    const int32_t *occ; const uint8_t *anchor; double *out; long long n;
+};
+
+__global__ __launch_bounds__(256) void rates_kernel(const RatesArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const Model &M = a.m;
+    const int p = a.pos[i], L = M.L;
+    int l = p - 1, r = p + 1;
+    if (M.periodic) { l = l < 0 ? l + L : l; r = r >= L ? r - L : r; }
+    else { l = l < 0 ? 0 : l; r = r > L - 1 ? L - 1 : r; }
+    const Channels c = channels(M, a.anchor ? a.anchor[p] != 0 : false, p, a.sigma[i], a.bound[i] != 0, a.m_field[p], a.beta,
+                                a.occ[p], a.occ[l], a.occ[r]);
+    const double v[9] = {c.diff, c.act, c.flip, c.bind, c.unbind, c.leave, c.left, c.right, c.total};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.out[(long long)k * a.n + i] = v[k];
+}
+
 // m-field on lattice sites: the same accumulation with the targets being sites instead of particles.
 struct FieldArgs {
     Model m; const long long *gsum;
@@ -1278,6 +1300,40 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_
     *pair_kernel_ms = total;
     if (launches) *launches = nsteps;
     if (pairs) *pairs = tiles * TILE * TILE;
+    return APS_OK;
+}
+
+int aps_rates_from_field(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *sigma, const uint8_t *bound, int64_t n,
+                         const double *m_field, const int64_t *counts_p, const int64_t *counts_m, double *out9n) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !pos || !sigma || !bound || !m_field || !counts_p || !counts_m || !out9n || n < 0)
+        return fail(h, APS_ERR_ARG, "aps_rates_from_field: bad argument");
+    if (n == 0) return APS_OK;
+    const int L = h->p.L;
+    for (int64_t i = 0; i < n; ++i)
+        if (pos[i] < 0 || pos[i] >= L) return fail(h, APS_ERR_ARG, "aps_rates_from_field: position outside [0, L)");
+    std::vector<int32_t> occ((size_t)L);
+    for (int x = 0; x < L; ++x) occ[(size_t)x] = (int32_t)(counts_p[x] + counts_m[x]);
+    void *d_pos = nullptr, *d_sig = nullptr, *d_bnd = nullptr, *d_m = nullptr, *d_occ = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() { for (void *q : {d_pos, d_sig, d_bnd, d_m, d_occ, d_out}) if (q) (void)hipFree(q); };
+#define TRY_(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); h->err = std::string(#expr) + ": " + hipGetErrorString(e_); return APS_ERR_HIP; } } while (0)
+    TRY_(hipMalloc(&d_pos, (size_t)n * 4)); TRY_(hipMalloc(&d_sig, (size_t)n)); TRY_(hipMalloc(&d_bnd, (size_t)n));
+    TRY_(hipMalloc(&d_m, (size_t)L * 8)); TRY_(hipMalloc(&d_occ, (size_t)L * 4)); TRY_(hipMalloc(&d_out, (size_t)n * 9 * 8));
+    TRY_(hipMemcpyAsync(d_pos, pos, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    TRY_(hipMemcpyAsync(d_sig, sigma, (size_t)n, hipMemcpyHostToDevice, h->stream));
+    TRY_(hipMemcpyAsync(d_bnd, bound, (size_t)n, hipMemcpyHostToDevice, h->stream));
+    TRY_(hipMemcpyAsync(d_m, m_field, (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
+    TRY_(hipMemcpyAsync(d_occ, occ.data(), (size_t)L * 4, hipMemcpyHostToDevice, h->stream));
+    RatesArgs a{};
+    a.m = h->model; a.beta = h->beta[(size_t)e]; a.pos = (const int32_t *)d_pos; a.sigma = (const int8_t *)d_sig;
+    a.bound = (const uint8_t *)d_bnd; a.m_field = (const double *)d_m; a.occ = (const int32_t *)d_occ; a.anchor = h->d_anchor;
+    a.out = (double *)d_out; a.n = n;
+    hipLaunchKernelGGL(rates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+    TRY_(hipGetLastError());
+    TRY_(hipMemcpyAsync(out9n, d_out, (size_t)n * 9 * 8, hipMemcpyDeviceToHost, h->stream));
+    TRY_(hipStreamSynchronize(h->stream));
+#undef TRY_
+    cleanup();
     return APS_OK;
 }
 

@@ -7,7 +7,10 @@ Differences that are part of the design:
     `dt` defaults to 0.1 / (largest possible total rate of one particle);
   * randomness inside `run` comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng` right
     after the initial condition, so a seeded `rng` still makes the whole run reproducible);
-  * `flip_rate_fn` must stay None (the Curie-Weiss rate exp(-beta*sigma*m) is evaluated on the GPU).
+  * `flip_rate_fn` must stay None (the Curie-Weiss rate exp(-beta*sigma*m) is evaluated on the GPU);
+  * `mode="gillespie"` (or calling `step_gillespie` yourself) runs the reference's exact one-event-per-iteration
+    loop instead, with the m-field and the rate vectors of every event computed on the GPU and the event drawn
+    from `rng` in the reference's call order.
 There is no CPU fallback: without libaps_hip.so or without a GPU, construction of the stepper raises.
 """
 from __future__ import annotations
@@ -27,7 +30,7 @@ class ParticleSystem:
                  site_capacity=1, crowding_suppresses_rates=False, k_on=0.1, k_off=0.01,
                  suppress_flip_when_bound=True, k_exit=0,
                  # extensions (all optional, after the reference's keywords)
-                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0):
+                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode="sync"):
         self.L = int(L)
         self.xlim = xlim
         self.K = int(site_capacity)
@@ -81,7 +84,11 @@ class ParticleSystem:
         self.device = int(device)
         self.sort_by_site = bool(sort_by_site)
         self.ensemble = int(ensemble)          # Philox counter word 3 (independent streams under one seed)
+        if mode not in ("sync", "gillespie"):
+            raise ValueError("mode must be 'sync' (fixed-dt stepper) or 'gillespie' (one exact event per iteration)")
+        self.mode = mode
         self._handle = None
+        self._util = None                      # lazily created handle for compute_local_m_field / step_gillespie
 
     # ------------------------------------------------------------------ initial conditions (host)
     def _init_fixed(self):
@@ -139,23 +146,146 @@ class ParticleSystem:
             crowding=self.crowding_suppresses_rates, k_on=self.k_on, k_off=self.k_off, k_exit=self.k_exit,
             anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site)
 
+    def _utility_handle(self):
+        if self._util is None:
+            self._util = self._make_handle(1, 0)
+        return self._util
+
+    def close(self):
+        if self._util is not None:
+            self._util.close()
+            self._util = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def compute_local_m_field(self, counts_p, counts_m):
         """m-field on all L sites for given site histograms (ref :216-246), evaluated on the GPU."""
-        h = self._handle or self._make_handle(1, 0)
-        try:
-            return h.field_from_counts(counts_p, counts_m)
-        finally:
-            if h is not self._handle:
-                h.close()
+        return self._utility_handle().field_from_counts(counts_p, counts_m)
 
-    def step_gillespie(self, *args, **kwargs):
-        raise NotImplementedError(
-            "step_gillespie (one exact Gillespie event, ref :254-448) is not part of the GPU path; "
-            "run() advances all particles synchronously with step dt")
+    def step_gillespie(self, pos, sigma, bound, m_field, counts_p, counts_m, init_bin, exit_times, exit_positions,
+                       exit_init_bin, t):
+        """One exact Gillespie event (ref :254-448), same arguments, in-place updates and return tuple.
+        The per-particle rate vectors are evaluated on the GPU (aps_rates_from_field); the waiting time, the
+        particle and the event are drawn from `self.rng` with the reference's call sequence
+        (exponential, choice(p=rates/R), random[, random])."""
+        n = sigma.size
+        if n == 0:
+            return pos, sigma, bound, np.inf, counts_p, counts_m
+        rt = self._utility_handle().rates_from_field(pos, sigma, bound, m_field, counts_p, counts_m)
+        rates = rt["total"]
+        R = float(rates.sum())
+        if R <= 0:
+            return pos, sigma, bound, np.inf, counts_p, counts_m
+        tau = self.rng.exponential(1.0 / R)
+        i = self.rng.choice(n, p=rates / R)
+        v = self.rng.random() * rates[i]
+        edge_diff = rt["diff"][i]
+        edge_act = edge_diff + rt["act"][i]
+        edge_bind = edge_act + rt["bind"][i]
+        edge_unbind = edge_bind + rt["unbind"][i]
+        edge_exit = edge_unbind + rt["exit"][i]
+        here = pos[i]
+        lane = counts_p if sigma[i] == 1 else counts_m
+
+        def hop(to):
+            to = to % self.L if self.periodic else min(max(to, 0), self.L - 1)
+            pos[i] = to
+            lane[here] -= 1
+            lane[to] += 1
+
+        if v < edge_diff:
+            a, b = rt["left"][i], rt["right"][i]
+            if a + b <= 0:
+                return pos, sigma, bound, tau, counts_p, counts_m
+            hop(here - 1 if self.rng.random() < a / (a + b) else here + 1)
+        elif v < edge_act:
+            hop(here + (1 if sigma[i] == 1 else 0))
+        elif v < edge_bind:
+            bound[i] = True
+        elif v < edge_unbind:
+            bound[i] = False
+        elif v < edge_exit:
+            exit_times.append(t)
+            exit_positions.append(pos[i])
+            exit_init_bin.append(int(init_bin[i]))
+            lane[here] -= 1
+            pos, sigma, bound = np.delete(pos, i), np.delete(sigma, i), np.delete(bound, i)
+        else:
+            other = counts_m if sigma[i] == 1 else counts_p
+            lane[here] -= 1
+            other[here] += 1
+            sigma[i] = -sigma[i]
+        return pos, sigma, bound, tau, counts_p, counts_m, exit_times, exit_positions, exit_init_bin
 
     # ------------------------------------------------------------------ run (ref :450-558)
     def run(self, T=10.0, obs_dt=0.01, record_fft=False, record_var=False):
+        if self.mode == "gillespie":
+            return self._run_gillespie(T, obs_dt, record_fft, record_var)
         return run_batched([self], T=T, obs_dt=obs_dt, record_fft=record_fft, record_var=record_var)[0]
+
+    def _run_gillespie(self, T, obs_dt, record_fft, record_var):
+        """The reference's event loop as written (ref :450-558): one event per iteration, observation after the
+        event that crossed the observation time, m_local_list = field from before that event.  The field and
+        the rate vectors of every event come from the GPU."""
+        L, dx = self.L, self.dx
+        pos, sigma = self.init_particles()
+        bound = np.zeros_like(sigma, dtype=bool)
+        times_obs = np.arange(0.0, T, obs_dt)
+        M = len(times_obs)
+        pos_list, particle_count_list, bound_list = [None] * M, [None] * M, [None] * M
+        rho_p_list, rho_m_list, total_list = np.zeros((M, L)), np.zeros((M, L)), np.zeros((M, L))
+        m_local_list, m_global = np.zeros((M, L)), np.zeros(M)
+        rho_hat_complex = np.zeros((M, L), dtype=complex) if record_fft else None
+        fft_amp_list = np.zeros((M, L)) if record_fft else None
+        var_list = np.zeros(M) if record_var else None
+        exit_times, exit_positions, exit_init_bin = [], [], []
+        init_bin = pos.copy()
+        counts_p = np.bincount(pos[sigma == 1], minlength=L)
+        counts_m = np.bincount(pos[sigma == -1], minlength=L)
+
+        def snapshot(k, field):
+            pos_list[k] = pos.copy()
+            rho_p, rho_m = self.empirical_densities_from_particles(pos, sigma, L, dx)
+            rho_p_list[k], rho_m_list[k], total_list[k] = rho_p, rho_m, rho_p + rho_m
+            particle_count_list[k] = pos.size
+            bound_list[k] = bound.copy()
+            m_local_list[k] = field
+            m_global[k] = np.mean(sigma)
+            if record_fft:
+                u = total_list[k]
+                spec = np.fft.fft(u)
+                rho_hat_complex[k], fft_amp_list[k] = spec, np.abs(spec)
+                if record_var:
+                    var_list[k] = float(np.var(u))
+
+        field = self.compute_local_m_field(counts_p, counts_m)
+        snapshot(0, field)
+        k, t, self.n_events = 1, 0.0, 0
+        while t < T:
+            field = self.compute_local_m_field(counts_p, counts_m)
+            ret = self.step_gillespie(pos, sigma, bound, field, counts_p, counts_m, init_bin, exit_times, exit_positions,
+                                      exit_init_bin, t)
+            pos, sigma, bound, tau = ret[0], ret[1], ret[2], ret[3]
+            self.n_events += 1
+            t += tau
+            if t > T:
+                break
+            while k < M and times_obs[k] <= t:
+                snapshot(k, field)
+                k += 1
+            if k >= M:
+                break
+        return {
+            "times_obs": times_obs, "pos_list": pos_list, "rho_p_list": rho_p_list, "rho_m_list": rho_m_list,
+            "total_list": total_list, "particle_count_list": particle_count_list, "bound_list": bound_list,
+            "m_local_list": m_local_list, "m_global": m_global, "rho_hat_complex": rho_hat_complex,
+            "fft_amp_list": fft_amp_list, "var_list": var_list, "exit_times": exit_times,
+            "exit_positions": exit_positions,
+        }
 
     # ------------------------------------------------------------------ the one plotting method a driver uses
     def plot_individuals(self, out, show_k_max=6, cmap_name="viridis", xlim=1, fig_size=(10, 6)):

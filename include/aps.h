@@ -106,6 +106,13 @@ int aps_observe(aps_handle *h, int32_t ensemble, int64_t *counts_p, int64_t *cou
 int aps_field_from_counts(aps_handle *h, int32_t ensemble, const int64_t *counts_p, const int64_t *counts_m,
                           double *m_field);
 
+/* replaces the rate section of step_gillespie (ref :254-352) for CALLER-supplied arrays (n particles, the
+ * m-field and the site histograms the reference passes in): out9n[c*n + i], c = diffusion, active, flip, bind,
+ * unbind, exit, left, right, total.  The event choice itself (ref :358-448) stays with the caller's generator. */
+int aps_rates_from_field(aps_handle *h, int32_t ensemble, const int32_t *pos, const int8_t *sigma, const uint8_t *bound,
+                         int64_t n, const double *m_field, const int64_t *counts_p, const int64_t *counts_m,
+                         double *out9n);
+
 int aps_time(aps_handle *h, double *t, int64_t *step_index);
 
 /* Exit log (ref :424-436): rows of (time, position, particle index), ordered by (time, index). */

@@ -129,3 +129,79 @@ def test_batched_beta_sweep_equals_separate_runs():
             e += 1
     # ordered phase at beta = 2.5 vs disordered at 0
     assert abs(res["m_means"][2]) > abs(res["m_means"][0])
+
+
+class _ForcedRng:
+    def __init__(self, i, uniforms):
+        self.i, self.u, self.scale, self.p = i, list(uniforms), None, None
+
+    def exponential(self, scale):
+        self.scale = float(scale)
+        return 0.125
+
+    def choice(self, n, p=None):
+        self.p = np.array(p)
+        return self.i
+
+    def random(self):
+        return self.u.pop(0)
+
+
+def test_step_gillespie_method_matches_reference_events(golden):
+    """The public step_gillespie (reference :254-448) with GPU-evaluated rates, replaying fixture G2: every forced
+    event must leave exactly the reference's state; rates/R agree to 1e-14."""
+    from PARTICLE_solver_CLASS import ParticleSystem
+    g = golden("g2_events.npz")
+    for s_idx, sc in enumerate(g.meta["cases"]):
+        ps = ParticleSystem(rng=np.random.default_rng(0), **sc["ctor"])
+        L = sc["ctor"]["L"]
+        pos0 = g[f"s{s_idx}_pos0"].astype(np.int64)
+        sigma0, bound0 = g[f"s{s_idx}_sigma0"], g[f"s{s_idx}_bound0"]
+        m_field = g[f"s{s_idx}_m_field"]
+        try:
+            for e, ev in enumerate(sc["events"]):
+                pos, sigma, bound = pos0.copy(), sigma0.copy(), bound0.copy()
+                cp = np.bincount(pos[sigma == 1], minlength=L)
+                cm = np.bincount(pos[sigma == -1], minlength=L)
+                ps.rng = _ForcedRng(ev["i"], [ev["u_v"], ev["u_lr"]])
+                ex_t, ex_p, ex_b = [], [], []
+                ret = ps.step_gillespie(pos, sigma, bound, m_field, cp, cm, pos0.copy(), ex_t, ex_p, ex_b, 1.5)
+                assert len(ret) == 9
+                pos, sigma, bound, tau = ret[0], ret[1], ret[2], ret[3]
+                np.testing.assert_allclose(ps.rng.p, g[f"s{s_idx}_p"][e], rtol=1e-14, atol=1e-18)
+                n1 = int(g[f"s{s_idx}_n1"][e])
+                assert len(pos) == n1 and np.array_equal(pos, g[f"s{s_idx}_pos1"][e][:n1])
+                assert np.array_equal(sigma, g[f"s{s_idx}_sigma1"][e][:n1])
+                assert np.array_equal(bound, g[f"s{s_idx}_bound1"][e][:n1].astype(bool))
+                assert np.array_equal(cp, g[f"s{s_idx}_cp1"][e]) and np.array_equal(cm, g[f"s{s_idx}_cm1"][e])
+                assert ex_t == ev["exit_t"] and [int(x) for x in ex_p] == ev["exit_p"] and ex_b == ev["exit_b"]
+        finally:
+            ps.close()
+
+
+def test_gillespie_mode_reproduces_reference_trajectories(golden):
+    """run(mode='gillespie'): the reference's exact event loop with the field and the rates on the GPU reproduces
+    the reference's SEEDED trajectories (fixture G3) -- integer state exactly, m-field to the weight-grid bound."""
+    from PARTICLE_solver_CLASS import ParticleSystem
+    g = golden("g3_trajectories.npz")
+    for idx, c in enumerate(g.meta["cases"]):
+        kw = dict(c["ctor"])
+        if c["poisson"]:
+            kw["rho0_plus"] = table_callable(g[f"c{idx}_rho0_plus"])
+            kw["rho0_minus"] = table_callable(g[f"c{idx}_rho0_minus"])
+        ps = ParticleSystem(rng=np.random.default_rng(c["seed"]), mode="gillespie", **kw)
+        try:
+            out = ps.run(**c["run"])
+        finally:
+            ps.close()
+        pre = f"c{idx}_"
+        assert np.array_equal(np.concatenate(out["pos_list"]), g[pre + "pos_cat"]), c["tag"]
+        assert np.array_equal(np.concatenate(out["bound_list"]), g[pre + "bound_cat"])
+        assert out["particle_count_list"] == g[pre + "particle_count"].tolist()
+        for k in ("rho_p_list", "rho_m_list", "total_list", "m_global"):
+            assert np.array_equal(out[k], g[pre + k]), (c["tag"], k)
+        # periodic case: the reference's own FFT round-off dominates where the Gaussian mass is tiny
+        tol = 1e-7 if c["ctor"].get("periodic") else 2e-11
+        assert np.max(np.abs(out["m_local_list"] - g[pre + "m_local_list"])) <= tol
+        assert np.array_equal(np.array(out["exit_times"], dtype=float), g[pre + "exit_times"])
+        assert np.array_equal(np.array(out["exit_positions"], dtype=np.int64), g[pre + "exit_positions"])
