@@ -165,43 +165,36 @@ constexpr int G = APS_G;                      // sources per group = G/4 broadca
 constexpr int NACC = 4;                       // independent accumulator chains (sums are exact: order-free)
 
 // G sources (already broadcast into registers: the same value in every lane) against this lane's target.
-// Per pair: v_sad_u32 -> ds_read_b64 (table gather) -> v_add_f64 (W) -> v_fma_f64 (S, sign from the wave mask).
+// Per pair: v_sad_u32 -> ds_read_b64 (table gather) -> v_add_f64.  The tile's sources are spin-partitioned
+// (plus first), so a group usually has ONE sign and adds into a single accumulator set (P = sum over plus
+// sources, M = sum over minus sources; W = P + M and S = P - M are exact on the weight grid).  `cut` = number
+// of leading plus sources in the group: cut >= G all plus, cut <= 0 all minus, else the mixed group.
 //   V_FAST    every pair of the tile block is inside the table's reach and farther than one site: no clamp
 //   V_GENERIC clamp to the zero entry behind the table; track the smallest distance for the occupancy branch
 //   V_MIRROR  additionally the reflected images (distance p_i + p_j + 1 mod 2L)
 template <int BC, int VAR, bool TAB_LDS>
-__device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const uint64_t signs, const uint32_t pi8, const uint32_t tbase,
-                                                 const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
-                                                 double (&accW)[NACC], double (&accS)[NACC], int &c0, int &cl, int &cr) {
+__device__ __forceinline__ void group_weights(const uint32_t (&p8)[G], const uint32_t pi8, const uint32_t tbase,
+                                              const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
+                                              double (&wt)[G], int &c0, int &cl, int &cr) {
     uint32_t near = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < G; ++k) {
-        double wt;
         if (VAR == V_FAST) {
-#if defined(APS_ABL_NOLDS)          /* timing-only ablations (wrong results): no table read at all */
-            wt = (double)sad3(pi8, p8[k], tbase);
+#if defined(APS_ABL_NOLDS)          /* timing-only ablation (wrong results): no table read at all */
+            wt[k] = (double)sad3(pi8, p8[k], tbase);
 #else
-            // every APS_TA_EVERY-th gather goes through the vector L1 path (same table in global memory): the
-            // texture-addresser pipe works in parallel with the LDS pipe, which is the busier one
-            if (TAB_LDS && APS_TA_EVERY > 0 && (k % (APS_TA_EVERY > 0 ? APS_TA_EVERY : 1)) == 0)
-                wt = table_at<false>(table_g, sad3(pi8, p8[k], 0u));
-            else
-                wt = table_at<TAB_LDS>(table_g, sad3(pi8, p8[k], tbase));
+            wt[k] = table_at<TAB_LDS>(table_g, sad3(pi8, p8[k], tbase));
 #endif
         } else {
             const uint32_t d8 = sad3(pi8, p8[k], 0u);
             const uint32_t t8 = (BC == 1) ? min(d8, L8 - d8) : d8;      // circular distance on the torus
-            wt = table_at<TAB_LDS>(table_g, min(t8, tlen8) + tbase);
+            wt[k] = table_at<TAB_LDS>(table_g, min(t8, tlen8) + tbase);
             if (VAR == V_MIRROR) {
                 const uint32_t s8 = pi8 + p8[k] + 8u;
-                wt += table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
+                wt[k] += table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
             }
             near = min(near, t8);
         }
-        accW[k % NACC] += wt;
-#ifndef APS_ABL_NOFMA
-        accS[k % NACC] = fma(wt, __hiloint2double((signs >> k) & 1ull ? (int)SG_PLUS : (int)SG_MINUS, 0), accS[k % NACC]);
-#endif
     }
     if (VAR != V_FAST && near <= 8u) {                       // rare: same or neighbouring site -> occupancy
 #pragma unroll
@@ -211,6 +204,28 @@ __device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const 
             c0 += (dlt == 0);
             cr += (dlt == 8) | (BC == 1 && dlt == 8 - (int)L8);
             cl += (dlt == -8) | (BC == 1 && dlt == (int)L8 - 8);
+        }
+    }
+}
+
+template <int BC, int VAR, bool TAB_LDS>
+__device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const int cut, const uint32_t pi8, const uint32_t tbase,
+                                                 const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
+                                                 double (&accP)[NACC], double (&accM)[NACC], int &c0, int &cl, int &cr) {
+    double wt[G];
+    group_weights<BC, VAR, TAB_LDS>(p8, pi8, tbase, table_g, tlen8, L8, wt, c0, cl, cr);
+    if (cut >= G) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) accP[k % NACC] += wt[k];
+    } else if (cut <= 0) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) accM[k % NACC] += wt[k];
+    } else {                                                 // at most one such group per tile
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const double sp = k < cut ? 1.0 : 0.0;
+            accP[k % NACC] = fma(wt[k], sp, accP[k % NACC]);
+            accM[k % NACC] = fma(wt[k], 1.0 - sp, accM[k % NACC]);
         }
     }
 }
@@ -242,14 +257,18 @@ __device__ __forceinline__ int tile_variant(int tlo, int thi, const int4 sb, int
 
 // One source tile against this lane's target.  `word` is the tile's source word of THIS lane (lane = source:
 // site*8 | spin-plus in bit 0, or the far sentinel for dead slots), fetched earlier by one coalesced vector
-// load.  The wave parks the 64 sites in its private LDS ring slot and reads them back 4 at a time with
-// broadcast ds_read_b128, so every lane holds every source; the spins become a wave mask by one ballot.
+// load.  The wave parks the 64 sites in its private LDS ring slot -- plus spins first (ballot + mbcnt
+// compaction) -- and reads them back 4 at a time with broadcast ds_read_b128, so every lane holds every source.
 template <int BC, bool TAB_LDS>
 __device__ __forceinline__ void process_tile(const uint32_t var, const uint32_t word, uint32_t *ring, const uint32_t pi8,
                                              const uint32_t tbase, const double *__restrict__ table_g, const uint32_t tlen8,
-                                             const uint32_t L8, double (&accW)[NACC], double (&accS)[NACC], int &c0, int &cl, int &cr) {
-    const uint64_t mask = __ballot((word & 1u) != 0u);
-    ring[threadIdx.x & 63] = word & ~7u;
+                                             const uint32_t L8, double (&accP)[NACC], double (&accM)[NACC], int &c0, int &cl, int &cr) {
+    const bool plus = (word & 1u) != 0u;
+    const uint64_t pm = __ballot(plus);
+    const int nplus = __popcll(pm);
+    const int lane = threadIdx.x & 63;
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+    ring[plus ? below : nplus + (lane - below)] = word & ~7u;
     const uint4 *ring4 = reinterpret_cast<const uint4 *>(ring);
 #pragma unroll 1
     for (int g = 0; g < TILE; g += G) {
@@ -259,9 +278,10 @@ __device__ __forceinline__ void process_tile(const uint32_t var, const uint32_t 
             const uint4 v = ring4[g / 4 + k];                // uniform address: LDS broadcast
             p8[4 * k] = v.x; p8[4 * k + 1] = v.y; p8[4 * k + 2] = v.z; p8[4 * k + 3] = v.w;
         }
-        if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS>(p8, mask >> g, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
-        else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS>(p8, mask >> g, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
-        else group_accumulate<BC, V_MIRROR, TAB_LDS>(p8, mask >> g, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+        const int cut = nplus - g;
+        if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
+        else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
+        else group_accumulate<BC, V_MIRROR, TAB_LDS>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
     }
 }
 
@@ -278,9 +298,9 @@ __device__ __forceinline__ unsigned accumulate_item(const uint32_t *__restrict__
                                                     double &accW_out, double &accS_out, int &c0, int &cl, int &cr) {
     const uint32_t tlen8 = (uint32_t)tlen << 3, L8 = (uint32_t)L << 3;
     const int lane = threadIdx.x & 63;
-    double accW[NACC], accS[NACC];
+    double accP[NACC], accM[NACC];                           // sums of weights over plus / minus sources
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) accW[k] = accS[k] = 0.0;
+    for (int k = 0; k < NACC; ++k) accP[k] = accM[k] = 0.0;
     unsigned done = 0;
     if (pn <= PLAN_CAP) {
         const int cnt = pn > q ? (pn - q + split - 1) / split : 0;       // entries of this share
@@ -300,7 +320,7 @@ __device__ __forceinline__ unsigned accumulate_item(const uint32_t *__restrict__
                     ent = (uint32_t)__builtin_amdgcn_readlane((int)my_ent, k + 1);
                     nxt = APS_SRC(ent);
                 }
-                process_tile<BC, TAB_LDS>(var, cur, ring, pi8, tbase, table_g, tlen8, L8, accW, accS, c0, cl, cr);
+                process_tile<BC, TAB_LDS>(var, cur, ring, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
                 ++done;
             }
         }
@@ -317,14 +337,15 @@ __device__ __forceinline__ unsigned accumulate_item(const uint32_t *__restrict__
                 if ((int)(seen++ % (unsigned)split) != q) continue;
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(var, b);
                 process_tile<BC, TAB_LDS>(v, sp8_e[(size_t)(base + b) * TILE + lane], ring, pi8, tbase, table_g, tlen8, L8,
-                                          accW, accS, c0, cl, cr);
+                                          accP, accM, c0, cl, cr);
                 ++done;
             }
         }
     }
 #pragma unroll
-    for (int k = 1; k < NACC; ++k) { accW[0] += accW[k]; accS[0] += accS[k]; }
-    accW_out += accW[0]; accS_out += accS[0];
+    for (int k = 1; k < NACC; ++k) { accP[0] += accP[k]; accM[0] += accM[k]; }
+    accW_out += accP[0] + accM[0];                           // exact on the weight grid
+    accS_out += accP[0] - accM[0];
     return done;
 }
 
