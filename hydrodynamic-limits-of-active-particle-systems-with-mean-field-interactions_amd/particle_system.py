@@ -287,6 +287,15 @@ class ParticleSystem:
             "exit_positions": exit_positions,
         }
 
+    # ------------------------------------------------------------------ presentation-only methods of the reference
+    def visualize_all(self, *args, **kwargs):
+        raise NotImplementedError("visualize_all (matplotlib figures, reference :561-661) is presentation code "
+                                  "outside the accelerated path; plot the returned `out` dictionary yourself")
+
+    def animate_profiles(self, *args, **kwargs):
+        raise NotImplementedError("animate_profiles (vispy animation, reference :980-1093) is presentation code "
+                                  "outside the accelerated path")
+
     # ------------------------------------------------------------------ the one plotting method a driver uses
     def plot_individuals(self, out, show_k_max=6, cmap_name="viridis", xlim=1, fig_size=(10, 6)):
         """Returns mean_v_eff like the reference (ref :901-906, :978); the PNG output of the

@@ -205,3 +205,32 @@ def test_gillespie_mode_reproduces_reference_trajectories(golden):
         assert np.max(np.abs(out["m_local_list"] - g[pre + "m_local_list"])) <= tol
         assert np.array_equal(np.array(out["exit_times"], dtype=float), g[pre + "exit_times"])
         assert np.array_equal(np.array(out["exit_positions"], dtype=np.int64), g[pre + "exit_positions"])
+
+
+def test_exclusion_driver_call_sequence():
+    """The exact constructor keywords and calls of the reference's single-run driver
+    (PARTICLE_solver_BIOLOGY_EXCLUSION.py:55-107; BASELINE config 1 parameters) work unchanged on the GPU class."""
+    from PARTICLE_solver_CLASS import ParticleSystem
+
+    def density_callable(L, scale):          # stands in for the driver's make_exp_gradient()[0/1] (unused with init='fixed')
+        table = scale * np.exp(-np.arange(L) / float(L) / 0.2)
+        return lambda x: float(table[int(np.clip(np.round(x * L), 0, L - 1))])
+
+    ps = ParticleSystem(
+        L=1000, xlim=1, rate_diffusion=0, rate_active=5, beta=0.7, flip_rate_fn=None, init='fixed',
+        rho0_plus=density_callable(1000, 3.0), rho0_minus=density_callable(1000, 0.5), N=750, scale_rates=False,
+        local_kernel_sigma=0.002, minus_anchor=True, periodic=False, immobilize_when_anchored=True,
+        anchor_radius=0.003, anchor_positions=None, site_capacity=3, crowding_suppresses_rates=False,
+        k_on=0, k_off=0, k_exit=0, rng=np.random.default_rng(2024))
+    out = ps.run(T=20, obs_dt=0.5, record_fft=True, record_var=True)
+    mean_v_eff = ps.plot_individuals(out, show_k_max=5, cmap_name='viridis', xlim=1)
+    assert ps.L == 1000 and ps.dx == 1e-3 and ps.K == 3
+    assert len(out["times_obs"]) == 40 and out["total_list"].shape == (40, 1000)
+    assert all(c == 750 for c in out["particle_count_list"])
+    assert max(np.bincount(p, minlength=1000).max() for p in out["pos_list"]) <= 3
+    assert out["fft_amp_list"] is not None and out["var_list"] is not None and out["exit_times"] == []
+    com = np.array([p.mean() for p in out["pos_list"]]) * ps.dx
+    assert com[-1] > com[0] + 0.02, "active + particles must drift to the right"
+    assert np.isfinite(mean_v_eff)
+    with pytest.raises(NotImplementedError):
+        ps.visualize_all(out)
