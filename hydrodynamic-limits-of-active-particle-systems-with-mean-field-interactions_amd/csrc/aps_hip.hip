@@ -156,13 +156,14 @@ __device__ __forceinline__ double table_at(const double *__restrict__ table_g, u
 }
 
 #ifndef APS_G
-#define APS_G 16
+#define APS_G 8
 #endif
 #ifndef APS_TA_EVERY
 #define APS_TA_EVERY 0                        // 0: all table gathers from LDS
 #endif
 constexpr int G = APS_G;                      // sources per group = G/4 broadcast ds_read_b128
-constexpr int NACC = 4;                       // independent accumulator chains (sums are exact: order-free)
+constexpr int NACC = 2;                       // independent accumulator chains per sum (sums are exact: order-free)
+constexpr int RT = 2;                         // target tiles per work item in pair_accumulate (each lane owns RT targets)
 
 // G sources (already broadcast into registers: the same value in every lane) against this lane's target.
 // Per pair: v_sad_u32 -> ds_read_b64 (table gather) -> v_add_f64.  The tile's sources are spin-partitioned
@@ -208,24 +209,33 @@ __device__ __forceinline__ void group_weights(const uint32_t (&p8)[G], const uin
     }
 }
 
-template <int BC, int VAR, bool TAB_LDS>
-__device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const int cut, const uint32_t pi8, const uint32_t tbase,
+template <int BC, int VAR, bool TAB_LDS, int R>
+__device__ __forceinline__ void group_accumulate(const uint32_t (&p8)[G], const int cut, const uint32_t (&pi8)[R], const uint32_t tbase,
                                                  const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
-                                                 double (&accP)[NACC], double (&accM)[NACC], int &c0, int &cl, int &cr) {
-    double wt[G];
-    group_weights<BC, VAR, TAB_LDS>(p8, pi8, tbase, table_g, tlen8, L8, wt, c0, cl, cr);
+                                                 double (&accP)[R][NACC], double (&accM)[R][NACC], int (&cnt)[R][3]) {
+    double wt[R][G];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        group_weights<BC, VAR, TAB_LDS>(p8, pi8[r], tbase, table_g, tlen8, L8, wt[r], cnt[r][0], cnt[r][1], cnt[r][2]);
     if (cut >= G) {
 #pragma unroll
-        for (int k = 0; k < G; ++k) accP[k % NACC] += wt[k];
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+            for (int r = 0; r < R; ++r) accP[r][k % NACC] += wt[r][k];
     } else if (cut <= 0) {
 #pragma unroll
-        for (int k = 0; k < G; ++k) accM[k % NACC] += wt[k];
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+            for (int r = 0; r < R; ++r) accM[r][k % NACC] += wt[r][k];
     } else {                                                 // at most one such group per tile
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const double sp = k < cut ? 1.0 : 0.0;
-            accP[k % NACC] = fma(wt[k], sp, accP[k % NACC]);
-            accM[k % NACC] = fma(wt[k], 1.0 - sp, accM[k % NACC]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                accP[r][k % NACC] = fma(wt[r][k], sp, accP[r][k % NACC]);
+                accM[r][k % NACC] = fma(wt[r][k], 1.0 - sp, accM[r][k % NACC]);
+            }
         }
     }
 }
@@ -259,10 +269,10 @@ __device__ __forceinline__ int tile_variant(int tlo, int thi, const int4 sb, int
 // site*8 | spin-plus in bit 0, or the far sentinel for dead slots), fetched earlier by one coalesced vector
 // load.  The wave parks the 64 sites in its private LDS ring slot -- plus spins first (ballot + mbcnt
 // compaction) -- and reads them back 4 at a time with broadcast ds_read_b128, so every lane holds every source.
-template <int BC, bool TAB_LDS>
-__device__ __forceinline__ void process_tile(const uint32_t var, const uint32_t word, uint32_t *ring, const uint32_t pi8,
+template <int BC, bool TAB_LDS, int R>
+__device__ __forceinline__ void process_tile(const uint32_t var, const uint32_t word, uint32_t *ring, const uint32_t (&pi8)[R],
                                              const uint32_t tbase, const double *__restrict__ table_g, const uint32_t tlen8,
-                                             const uint32_t L8, double (&accP)[NACC], double (&accM)[NACC], int &c0, int &cl, int &cr) {
+                                             const uint32_t L8, double (&accP)[R][NACC], double (&accM)[R][NACC], int (&cnt)[R][3]) {
     const bool plus = (word & 1u) != 0u;
     const uint64_t pm = __ballot(plus);
     const int nplus = __popcll(pm);
@@ -279,74 +289,87 @@ __device__ __forceinline__ void process_tile(const uint32_t var, const uint32_t 
             p8[4 * k] = v.x; p8[4 * k + 1] = v.y; p8[4 * k + 2] = v.z; p8[4 * k + 3] = v.w;
         }
         const int cut = nplus - g;
-        if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
-        else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
-        else group_accumulate<BC, V_MIRROR, TAB_LDS>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
+        if (var == V_FAST) group_accumulate<BC, V_FAST, TAB_LDS, R>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, cnt);
+        else if (var == V_GENERIC) group_accumulate<BC, V_GENERIC, TAB_LDS, R>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, cnt);
+        else group_accumulate<BC, V_MIRROR, TAB_LDS, R>(p8, cut, pi8, tbase, table_g, tlen8, L8, accP, accM, cnt);
     }
 }
 
-// Accumulation of one work item by ONE wave: target tile (lane = target) against share `q` of `split` of its
-// source tiles.  Planned path: the wave's list entries are fetched with one vector load (lane k = k-th entry
-// of the share) and the source tiles are streamed one tile ahead (vmcnt), so no memory latency is exposed in
-// the steady state.  Overflow path (list longer than PLAN_CAP, e.g. unsorted particles): the wave scans the
-// tile infos itself, 64 at a time.  No barrier anywhere.
-template <int BC, bool TAB_LDS>
+// Accumulation of one work item by ONE wave: R consecutive target tiles (each lane owns R targets, one per
+// tile) against share `q` of `split` of the source tiles of that target group.  Planned path: the wave's list
+// entries are fetched with one vector load (lane k = k-th entry of the share) and the source tiles are
+// streamed one tile ahead (vmcnt), so no memory latency is exposed in the steady state.  Overflow path (list
+// longer than PLAN_CAP, e.g. unsorted particles): the wave scans the tile infos itself, 64 at a time.
+// `tb` = merged info of the target group.  No barrier anywhere.
+template <int BC, bool TAB_LDS, int R>
 __device__ __forceinline__ unsigned accumulate_item(const uint32_t *__restrict__ entries, const int pn, const int q, const int split,
                                                     const uint32_t *__restrict__ sp8_e, const int4 *__restrict__ tinfo_e,
-                                                    const int ntiles, const int4 tb, const uint32_t pi8, const uint32_t tbase,
+                                                    const int ntiles, const int4 tb, const uint32_t (&pi8)[R], const uint32_t tbase,
                                                     uint32_t *ring, const double *__restrict__ table_g, const int tlen, const int L,
-                                                    double &accW_out, double &accS_out, int &c0, int &cl, int &cr) {
+                                                    double (&outW)[R], double (&outS)[R], int (&cnt)[R][3]) {
     const uint32_t tlen8 = (uint32_t)tlen << 3, L8 = (uint32_t)L << 3;
     const int lane = threadIdx.x & 63;
-    double accP[NACC], accM[NACC];                           // sums of weights over plus / minus sources
+    double accP[R][NACC], accM[R][NACC];                     // sums of weights over plus / minus sources
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) accP[k] = accM[k] = 0.0;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) accP[r][k] = accM[r][k] = 0.0;
     unsigned done = 0;
     if (pn <= PLAN_CAP) {
-        const int cnt = pn > q ? (pn - q + split - 1) / split : 0;       // entries of this share
-        for (int c = 0; c < cnt; c += TILE) {
-            const int n = min(TILE, cnt - c);
+        const int n_mine = pn > q ? (pn - q + split - 1) / split : 0;    // entries of this share
+        for (int c = 0; c < n_mine; c += TILE) {
+            const int n = min(TILE, n_mine - c);
             const uint32_t my_ent = lane < n ? entries[q + (size_t)(c + lane) * split] : 0u;
             uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)my_ent, 0);
-#ifdef APS_ABL_NOSRC                /* timing-only ablation: synthetic source words, no loads in the tile loop */
-#define APS_SRC(e_) ((((e_) & 0x0FFFFFFFu) * 1024u + (uint32_t)lane * 16u) | 1u)
-#else
-#define APS_SRC(e_) sp8_e[(size_t)((e_) & 0x0FFFFFFFu) * TILE + lane]
-#endif
-            uint32_t nxt = APS_SRC(ent);
+            uint32_t nxt = sp8_e[(size_t)(ent & 0x0FFFFFFFu) * TILE + lane];
             for (int k = 0; k < n; ++k) {
                 const uint32_t cur = nxt, var = ent >> 28;
                 if (k + 1 < n) {                             // next tile's sources are in flight during this tile
                     ent = (uint32_t)__builtin_amdgcn_readlane((int)my_ent, k + 1);
-                    nxt = APS_SRC(ent);
+                    nxt = sp8_e[(size_t)(ent & 0x0FFFFFFFu) * TILE + lane];
                 }
-                process_tile<BC, TAB_LDS>(var, cur, ring, pi8, tbase, table_g, tlen8, L8, accP, accM, c0, cl, cr);
+                process_tile<BC, TAB_LDS, R>(var, cur, ring, pi8, tbase, table_g, tlen8, L8, accP, accM, cnt);
                 ++done;
             }
         }
     } else {
-        const int R = tlen > 1 ? tlen - 1 : 1, Rtab = tlen - 1;
+        const int Rr = tlen > 1 ? tlen - 1 : 1, Rtab = tlen - 1;
         unsigned seen = 0;
         for (int base = 0; base < ntiles; base += 64) {
             const int jt = base + lane;
-            const int var = jt < ntiles ? tile_variant<BC>(tb.x, tb.y, tinfo_e[jt], R, Rtab, L, tb.z == 0) : -1;
+            const int var = jt < ntiles ? tile_variant<BC>(tb.x, tb.y, tinfo_e[jt], Rr, Rtab, L, tb.z == 0) : -1;
             unsigned long long m = __ballot(var >= 0);
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
                 if ((int)(seen++ % (unsigned)split) != q) continue;
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(var, b);
-                process_tile<BC, TAB_LDS>(v, sp8_e[(size_t)(base + b) * TILE + lane], ring, pi8, tbase, table_g, tlen8, L8,
-                                          accP, accM, c0, cl, cr);
+                process_tile<BC, TAB_LDS, R>(v, sp8_e[(size_t)(base + b) * TILE + lane], ring, pi8, tbase, table_g, tlen8, L8,
+                                             accP, accM, cnt);
                 ++done;
             }
         }
     }
 #pragma unroll
-    for (int k = 1; k < NACC; ++k) { accP[0] += accP[k]; accM[0] += accM[k]; }
-    accW_out += accP[0] + accM[0];                           // exact on the weight grid
-    accS_out += accP[0] - accM[0];
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 1; k < NACC; ++k) { accP[r][0] += accP[r][k]; accM[r][0] += accM[r][k]; }
+        outW[r] = accP[r][0] + accM[r][0];                   // exact on the weight grid
+        outS[r] = accP[r][0] - accM[r][0];
+    }
     return done;
+}
+
+// merged tile info of R consecutive tiles (bounds over the live particles, any-dead flag, live count)
+template <int R>
+__device__ __forceinline__ int4 merged_info(const int4 *__restrict__ tinfo_e, const int first_tile) {
+    int4 m = tinfo_e[first_tile];
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        const int4 t = tinfo_e[first_tile + r];
+        m.x = min(m.x, t.x); m.y = max(m.y, t.y); m.z |= t.z; m.w += t.w;   // empty tiles carry (INT_MAX, -1)
+    }
+    return m;
 }
 
 // Weight table global -> LDS with 8 independent loads in flight per thread (a plain loop waits for each load).
@@ -406,8 +429,9 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
     return c;
 }
 
-// plan<BC>: one wave per target tile lists the source tiles that can matter (tile index | loop variant << 28)
-// into plan[e][t][0..PLAN_CAP) and their number into plan_n[e][t] (a count > PLAN_CAP means "scan in-kernel").
+// plan<BC>: one wave per target group (RT consecutive tiles) lists the source tiles that can matter (tile index
+// | loop variant << 28) into plan[e][group][0..PLAN_CAP) and their number into plan_n[e][group] (a count >
+// PLAN_CAP means "scan in-kernel").
 // Correct for any particle order; short lists when the slots are site-sorted.
 struct PlanArgs { int L, tlen, ntiles, tile_lo, tile_cnt, margin; uint32_t *plan, *plan_n; };
 
@@ -415,12 +439,12 @@ template <int BC>
 __global__ __launch_bounds__(256) void plan_tiles(const PlanArgs a, const int4 *__restrict__ tinfo_all) {
     const int e = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tt >= a.tile_cnt) return;
-    const int ttile = a.tile_lo + tt;
+    const int gg = blockIdx.x * 4 + (threadIdx.x >> 6);       // target group within this rank's shard
+    if (gg >= a.tile_cnt / RT) return;
+    const int group = a.tile_lo / RT + gg;                    // global group index
     const int4 *__restrict__ tinfo_e = tinfo_all + (size_t)e * a.ntiles;
-    const int4 tb = tinfo_e[ttile];
-    uint32_t *out = a.plan + ((size_t)e * a.ntiles + ttile) * PLAN_CAP;
+    const int4 tb = merged_info<RT>(tinfo_e, group * RT);
+    uint32_t *out = a.plan + ((size_t)e * (a.ntiles / RT) + group) * PLAN_CAP;
     const int R = a.tlen > 1 ? a.tlen - 1 : 1, Rtab = a.tlen - 1;
     unsigned n = 0;
     if (tb.w > 0) {
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(256) void plan_tiles(const PlanArgs a, const int4 *
             }
         }
     }
-    if (lane == 0) a.plan_n[(size_t)e * a.ntiles + ttile] = n;
+    if (lane == 0) a.plan_n[(size_t)e * (a.ntiles / RT) + group] = n;
 }
 
 // pair_accumulate: the dominant kernel.  Persistent workgroups of 4 INDEPENDENT waves that share only the
@@ -472,7 +496,8 @@ __global__ __launch_bounds__(NTHREADS) void pair_accumulate(const PairArgs a, co
         __syncthreads();
     }
     uint32_t *ring = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + lds_table_bytes(a.tlen, TAB_LDS)) + wave * TILE;
-    const unsigned total_items = (unsigned)a.E * (unsigned)a.tile_cnt * (unsigned)a.split;
+    const unsigned ngroups = (unsigned)(a.tile_cnt / RT);     // target groups of this rank's shard
+    const unsigned total_items = (unsigned)a.E * ngroups * (unsigned)a.split;
     const unsigned nwaves = gridDim.x * WAVES;
 #ifdef APS_STAMPS
     unsigned long long t_fetch = 0, t_acc = 0, t_epi = 0, t_items = 0, t0 = __builtin_amdgcn_s_memtime(), t_start = t0;
@@ -481,37 +506,44 @@ __global__ __launch_bounds__(NTHREADS) void pair_accumulate(const PairArgs a, co
 #else
 #define STAMP(var)
 #endif
-    unsigned item = blockIdx.x * WAVES + wave;                // static first item: no stampede on the counter
+    unsigned item = blockIdx.x * WAVES + wave;                // static striding: wave w takes items w, w + nwaves, ...
     while (item < total_items) {
         const int q = (int)(item % (unsigned)a.split);
-        const unsigned tix = item / (unsigned)a.split;
-        const int e = (int)(tix / (unsigned)a.tile_cnt);
-        const int ttile = a.tile_lo + (int)(tix % (unsigned)a.tile_cnt);
+        const unsigned gix = item / (unsigned)a.split;
+        const int e = (int)(gix / ngroups);
+        const int group = a.tile_lo / RT + (int)(gix % ngroups);
         const uint32_t *__restrict__ sp8_e = sp8_all + (size_t)e * a.Npad;
         const int4 *__restrict__ tinfo_e = tinfo_all + (size_t)e * a.ntiles;
-        const size_t slot = (size_t)ttile * TILE + lane;
-        const uint32_t my_p8 = sp8_e[slot] & ~7u;
-        const uint32_t pi8 = my_p8 == DEAD_P8 ? 0u : my_p8;  // dead targets: any in-range site
-        const int4 tb = tinfo_e[ttile];
-        const int pn = (int)plan_n_all[(size_t)e * a.ntiles + ttile];
+        const size_t slot0 = (size_t)group * RT * TILE + lane;
+        uint32_t pi8[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const uint32_t w = sp8_e[slot0 + (size_t)r * TILE] & ~7u;
+            pi8[r] = w == DEAD_P8 ? 0u : w;                  // dead targets: any in-range site
+        }
+        const int4 tb = merged_info<RT>(tinfo_e, group * RT);
+        const size_t pidx = (size_t)e * (a.ntiles / RT) + group;
+        const int pn = (int)plan_n_all[pidx];
         STAMP(t_fetch)
-        double accW = 0.0, accS = 0.0;
-        int c0 = 0, cl = 0, cr = 0;
-        unsigned done = 0;
+        double accW[RT], accS[RT];
+        int cnt[RT][3];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { accW[r] = accS[r] = 0.0; cnt[r][0] = cnt[r][1] = cnt[r][2] = 0; }
         if (tb.w > 0)
-            done = accumulate_item<BC, TAB_LDS>(plan_all + ((size_t)e * a.ntiles + ttile) * PLAN_CAP, pn, q, a.split, sp8_e,
-                                                tinfo_e, a.ntiles, tb, pi8, tbase, ring, table_g, a.tlen, M.L, accW, accS, c0, cl, cr);
+            accumulate_item<BC, TAB_LDS, RT>(plan_all + pidx * PLAN_CAP, pn, q, a.split, sp8_e, tinfo_e, a.ntiles, tb, pi8, tbase,
+                                             ring, table_g, a.tlen, M.L, accW, accS, cnt);
         STAMP(t_acc)
 #ifdef APS_ABL_NOSTORE
-        if (accW == -1.0)
+        if (accW[0] == -1.0)
 #endif
-        {   // every (tile, share) item is evaluated exactly once per launch: plain stores, nothing to clear
-            const size_t o = ((size_t)q * a.E + e) * a.Npad + slot;
-            a.accW[o] = accW; a.accS[o] = accS;
-            a.occ[o] = (unsigned)c0 | ((unsigned)cl << 10) | ((unsigned)cr << 20);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {   // every (group, share) item is evaluated exactly once per launch: plain stores
+            const size_t o = ((size_t)q * a.E + e) * a.Npad + slot0 + (size_t)r * TILE;
+            a.accW[o] = accW[r]; a.accS[o] = accS[r];
+            a.occ[o] = (unsigned)cnt[r][0] | ((unsigned)cnt[r][1] << 10) | ((unsigned)cnt[r][2] << 20);
         }
-        item += nwaves;                                       // static striding: items cost about the same, and a single
-        STAMP(t_epi)                                          // dequeue counter saturates at ~88 grabs/us (measured)
+        item += nwaves;                                       // items cost about the same; a single dequeue counter
+        STAMP(t_epi)                                          // would saturate at ~88 grabs/us (measured)
 #ifdef APS_STAMPS
         t_items += 1;
 #endif
@@ -740,10 +772,12 @@ __global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const
     const int thi = min(tlo + TILE - 1, M.L - 1);
     const int x = tlo + lane;
     const uint32_t pi8 = (uint32_t)min(x, M.L - 1) << 3;
-    double accW = 0.0, accS = 0.0;
-    int c0 = 0, cl = 0, cr = 0;
-    accumulate_item<BC, TAB_LDS>(nullptr, PLAN_CAP + 1, 0, 1, sp8, tinfo, a.ntiles, make_int4(tlo, thi, 0, TILE), pi8, tbase, ring,
-                                 table_g, a.tlen, M.L, accW, accS, c0, cl, cr);
+    const uint32_t pi8v[1] = {pi8};
+    double accWv[1] = {0.0}, accSv[1] = {0.0};
+    int cnt[1][3] = {{0, 0, 0}};
+    accumulate_item<BC, TAB_LDS, 1>(nullptr, PLAN_CAP + 1, 0, 1, sp8, tinfo, a.ntiles, make_int4(tlo, thi, 0, TILE), pi8v, tbase, ring,
+                                    table_g, a.tlen, M.L, accWv, accSv, cnt);
+    double accW = accWv[0], accS = accSv[0];
     if (x >= M.L) return;
     if (M.field_mode == 0) { accS = (double)a.gsum[2 * a.e]; accW = (double)a.gsum[2 * a.e + 1]; }
     double mloc = 0.0;
@@ -969,7 +1003,7 @@ int launch_plan(aps_handle *h, int first_tile, int tile_cnt) {
     PlanArgs pa{h->p.L, h->tlen, (int)h->ntiles, first_tile, tile_cnt, h->plan_interval > 1 ? 2 * h->plan_interval : 0,
                 h->d_plan, h->d_plan_n};
     h->plan_age = 0;
-    const dim3 grid((unsigned)((tile_cnt + 3) / 4), (unsigned)h->E), block(256);
+    const dim3 grid((unsigned)((tile_cnt / RT + 3) / 4), (unsigned)h->E), block(256);
     if (h->p.periodic) hipLaunchKernelGGL(plan_tiles<1>, grid, block, 0, h->stream, pa, h->d_tinfo);
     else hipLaunchKernelGGL(plan_tiles<0>, grid, block, 0, h->stream, pa, h->d_tinfo);
     HIP_TRY(h, hipGetLastError());
@@ -991,13 +1025,13 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
     int split = 1;
     double best = 1e30;
     for (int sp = 1; sp <= MAX_SPLIT; ++sp) {
-        const double items = (double)tile_cnt * h->E * sp, rounds = std::ceil(items / slots);
+        const double items = (double)(tile_cnt / RT) * h->E * sp, rounds = std::ceil(items / slots);
         const double cost = rounds * slots / items * (1.0 + 0.02 * sp) * (rounds < 2 ? 1.5 : 1.0);   // waste x mild per-item overhead
         if (cost < best) { best = cost; split = sp; }
     }
     if (const char *env = std::getenv("APS_SPLIT")) split = std::max(1, std::min(MAX_SPLIT, std::atoi(env)));   // tuning knob
     b.split = h->split = split;
-    const unsigned items = (unsigned)tile_cnt * (unsigned)h->E * (unsigned)split;
+    const unsigned items = (unsigned)(tile_cnt / RT) * (unsigned)h->E * (unsigned)split;
     const dim3 grid(std::max(1u, std::min((items + WAVES - 1) / WAVES, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
 #define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_accumulate<BC, TL>), grid, block, lds, h->stream, b, h->d_sp8, h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
@@ -1036,6 +1070,13 @@ int set_lds_limit(aps_handle *h) {
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int by_lds = need ? (int)((160 * 1024) / need) : 8, by_waves = 16 / WAVES;   // 4 waves/SIMD saturate the LDS gather
     h->wgs_per_cu = std::max(1, std::min(by_lds, by_waves));
+    {   // registers may allow fewer resident workgroups than LDS does: ask the runtime for this kernel
+        int nb = 0;
+        const void *fn = h->p.periodic ? (h->table_in_lds ? (const void *)&pair_accumulate<1, true> : (const void *)&pair_accumulate<1, false>)
+                                       : (h->table_in_lds ? (const void *)&pair_accumulate<0, true> : (const void *)&pair_accumulate<0, false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NTHREADS, need) == hipSuccess && nb > 0)
+            h->wgs_per_cu = std::min(h->wgs_per_cu, nb);
+    }
     if (const char *env = std::getenv("APS_WGS_PER_CU")) h->wgs_per_cu = std::max(1, std::atoi(env));     // tuning knob
     return APS_OK;
 }
@@ -1295,8 +1336,8 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_
         HIP_TRY(h, hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    double tiles = 0.0;                                     // source tiles evaluated = sum of the planned list lengths
-    std::vector<uint32_t> pn((size_t)h->E * h->ntiles);
+    double tiles = 0.0;                                     // (target tile, source tile) blocks = RT x sum of the list lengths
+    std::vector<uint32_t> pn((size_t)h->E * (h->ntiles / RT));
     for (int64_t s = 0; s < nsteps; ++s) {
         int rc;
         HIP_TRY(h, hipEventRecord(h->events[(size_t)(2 * s)], h->stream));
@@ -1306,7 +1347,7 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_
             HIP_TRY(h, hipMemcpyAsync(pn.data(), h->d_plan_n, pn.size() * 4, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             double t = 0.0;
-            for (uint32_t v : pn) t += v;
+            for (uint32_t v : pn) t += (double)v * RT;
             tiles += t * (nsteps == 1 ? 1.0 : 0.5 * (double)nsteps);
         }
         if ((rc = do_commit(h))) return rc;
@@ -1412,7 +1453,7 @@ int aps_debug_stamps(aps_handle *h, unsigned long long *out, int64_t nwords) {
 int aps_debug_plan_n(aps_handle *h, uint32_t *out, int64_t n) {
     if (!h || !out) return APS_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out, h->d_plan_n, (size_t)std::min<int64_t>(n, h->ntiles) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->d_plan_n, (size_t)std::min<int64_t>(n, h->ntiles / RT) * 4, hipMemcpyDeviceToHost));
     return APS_OK;
 }
 
