@@ -34,7 +34,7 @@ EXTRA = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
-LDS_CYCLES_PER_64_PAIRS = 5.5  # measured: 4.5 per table gather (2.0 + 2.5 bank conflicts) + 1.0 source broadcast
+LDS_CYCLES_PER_64_PAIRS = 5.0  # measured (PMC 4.93): 4.5 per table gather (2.0 + 2.5 bank conflicts) + 0.5 source broadcast
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 FETCH_SIZE/WRITE_SIZE of this command
 
 
@@ -193,7 +193,7 @@ def main():
                 "on_chip": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs_per_s,
                             "lds_bound_pairs_per_s": lds_peak_pairs, "lds_frac": pairs_per_s / lds_peak_pairs,
                             "lds_cycles_per_64_pairs": LDS_CYCLES_PER_64_PAIRS,
-                            "valu_lane_ops_per_pair": 10, "valu_frac": pairs_per_s * 10 / VALU_LANE_OPS_PER_S}}
+                            "valu_issue_slots_per_pair": 4, "valu_frac": pairs_per_s * 4 / VALU_LANE_OPS_PER_S}}
     p, s, b, a = h.get_state()
     assert a.all() and np.bincount(p, minlength=w["L"]).max() <= w["K"]
     h.close()

@@ -124,8 +124,8 @@ int aps_get_table(aps_handle *h, double *out, int32_t cap, int32_t *tlen, int32_
 /* Re-establish the site-sorted internal order (no effect on results; speeds up tile culling). */
 int aps_resort(aps_handle *h);
 
-/* Measurement: run nsteps steps with HIP events around every launch of the all-pairs kernel on the
- * handle's stream; returns their summed duration, the number of launches and pair evaluations. */
+/* Measurement: run nsteps steps with HIP events around every launch of the all-pairs kernel (pair_accumulate
+ * alone) on the handle's stream; returns their summed duration, the number of launches and pair evaluations. */
 int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_t *launches,
                    double *pairs_evaluated);
 
