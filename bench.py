@@ -107,6 +107,20 @@ def cpu_reference_loop(w, budget_s=12.0):
             "sample": f"{n} Gillespie events (compute_local_m_field + step_gillespie restated in NumPy), {el:.1f} s"}
 
 
+class stdout_to_stderr:
+    """RCCL prints a banner to fd 1 while a communicator is created; the contract is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,19 +139,23 @@ def main():
         raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
     pos, spin = initial_state(w)
     roof, comm_path = None, ""
-    if world > 1:
+    sharded_path = world > 1 or os.environ.get("APS_BENCH_FORCE_SHARDED") == "1"   # the switch lets one rank rehearse it
+    if sharded_path:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo")                      # rendezvous / barriers only; the data path is RCCL below
+        with stdout_to_stderr():                             # gloo announces its connections on stdout
+            dist.init_process_group("gloo")                  # rendezvous / barriers only; the data path is RCCL below
         h = make_handle(capi, w, device=local_rank, rank=rank, world=world)
         h.set_state(pos, spin)
         # preferred: the library all-gathers the proposal bytes itself (ncclAllGather on its stream, no Python per step)
         ok, path = 1, "in-library RCCL all-gather"
         try:
-            ids = [capi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            h.comm_init(ids[0])
+            with stdout_to_stderr():
+                ids = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                h.comm_init(ids[0])
+                h.step(1)                                    # first collective (lazy channel setup) also under the redirect
         except Exception as exc:                             # noqa: BLE001
             ok = 0
             print(f"[rank {rank}] in-library RCCL unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
@@ -148,8 +166,10 @@ def main():
         else:                                                # every rank takes the fallback together
             sharded = importlib.import_module(PKG + ".sharded")
             path = "torch.distributed nccl all_gather_into_tensor"
-            group = dist.new_group(backend="nccl")
-            stepper = sharded.ShardedStepper(sharded.HipEngine(h, torch.device("cuda", local_rank)), group=group)
+            with stdout_to_stderr():
+                group = dist.new_group(backend="nccl")
+                stepper = sharded.ShardedStepper(sharded.HipEngine(h, torch.device("cuda", local_rank)), group=group)
+                stepper.step(1)
 
             def run(n):
                 stepper.step(n)
@@ -207,7 +227,7 @@ def main():
                                 "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on") if args.workload == "config2"
                                else f"BASELINE {args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma=0.005, dt=0.0125",
                    "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"
-                               + (f" ({comm_path})" if world > 1 else "")},
+                               + (f" ({comm_path})" if sharded_path else "")},
     }
     if roof:
         out["roofline"] = roof
