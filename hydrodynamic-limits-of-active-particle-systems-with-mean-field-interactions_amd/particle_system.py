@@ -5,7 +5,7 @@ dictionary (ref :542-557); the time loop runs in HIP kernels behind the C ABI of
 Differences that are part of the design:
   * time advances in fixed steps `dt` (synchronous scheme) instead of one Gillespie event at a time;
     `dt` defaults to 0.1 / (largest possible total rate of one particle);
-  * randomness inside `run` comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng` right
+  * randomness inside `run` comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng.random()` right
     after the initial condition, so a seeded `rng` still makes the whole run reproducible);
   * `flip_rate_fn` must stay None (the Curie-Weiss rate exp(-beta*sigma*m) is evaluated on the GPU);
   * `mode="gillespie"` (or calling `step_gillespie` yourself) runs the reference's exact one-event-per-iteration
@@ -330,7 +330,8 @@ def run_batched(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var=False
             raise ValueError("run_batched: systems differ in anchor sites")
     L, dx = first.L, first.dx
     inits = [ps.init_particles() for ps in systems]
-    seed = first.seed if first.seed is not None else int(first.rng.integers(0, 2 ** 63))
+    # the reference only requires choice / poisson / exponential / random of an rng object (ref :75-78)
+    seed = first.seed if first.seed is not None else int(first.rng.random() * 2.0 ** 53)
     if first.dt is None:
         first.dt = min(ps.default_dt() for ps in systems)
     for ps in systems:

@@ -404,3 +404,60 @@ def test_table_too_large_for_lds_uses_global_table(capi):
         assert np.array_equal(m, orc.field_sites()[2])
     finally:
         h.close()
+
+
+def _random_case(rng):
+    L = int(rng.choice([2, 3, 5, 17, 64, 129, 300, 777]))
+    K = int(rng.integers(1, 6))
+    sigma = float(rng.choice([0.0, 0.3 / L, 2.0 / L, 0.02, 0.11, 0.4]))
+    kw = dict(L=L, K=K, sigma=sigma, periodic=bool(rng.integers(2)),
+              rate_diffusion=float(rng.choice([0.0, 0.05, 1.5, 9.0])), rate_active=float(rng.choice([0.0, 0.7, 6.0])),
+              beta=float(rng.choice([0.0, 0.4, 1.7, 4.0])), minus_anchor=bool(rng.integers(2)),
+              immobilize_when_anchored=bool(rng.integers(2)), suppress_flip_when_bound=bool(rng.integers(2)),
+              crowding_suppresses_rates=bool(rng.integers(2)))
+    if rng.integers(2):
+        kw.update(anchor_positions=list(rng.random(int(rng.integers(1, 4)))), anchor_radius=float(rng.choice([0.0, 0.02, 0.2])),
+                  k_on=float(rng.choice([0.0, 0.5, 4.0])), k_off=float(rng.choice([0.0, 0.3, 2.0])),
+                  k_exit=float(rng.choice([0.0, 0.4, 3.0])))
+    else:
+        kw.update(k_on=0.0, k_off=0.0, k_exit=0.0)
+    return kw
+
+
+def test_randomised_parameter_sweep_bit_exact(capi):
+    """32 random parameter sets (tiny to medium lattices, K up to 5, every field mode, anchors, crowding, zero
+    rates, wrap-around, particles dead from the start) -- integer state bit-exact against the oracle along 60 steps,
+    S/W/occupancy and the m-field bit-exact at the start."""
+    master = np.random.default_rng(20261004)
+    for case_no in range(32):
+        rng = np.random.default_rng(master.integers(2 ** 32))
+        kw = _random_case(rng)
+        par = params(**kw)
+        N = int(max(1, rng.integers(1, par.L * par.K + 1) * rng.choice([0.2, 0.6, 1.0])))
+        pos, spin = random_state(rng, par.L, N, par.K)
+        alive = (rng.random(N) > 0.15).astype(np.uint8) if case_no % 3 == 0 else None
+        bound = (rng.random(N) > 0.6).astype(np.uint8) if case_no % 2 == 0 else None
+        dt, seed = float(rng.choice([0.002, 0.03, 0.2])), int(rng.integers(2 ** 62))
+        orc = so.SyncOracle(par, dt=dt, seed=seed)
+        orc.set_state(pos, spin, bound=bound, alive=alive)
+        h = make_handle(capi, par, N, dt=dt, seed=seed, sort_by_site=bool(case_no % 2))
+        try:
+            h.set_state(pos, spin, bound=bound, alive=alive)
+            S, W, occ4 = h.pair_accumulate()
+            S0, W0, occ0 = orc.pair_sums()
+            assert np.array_equal(S, S0) and np.array_equal(W, W0) and np.array_equal(occ4, occ0), (case_no, kw)
+            assert np.array_equal(h.observe()[2], orc.field_sites()[2]), (case_no, kw)
+            for chunk in range(6):
+                h.step(10)
+                orc.run(10)
+                p, sg, bd, al = h.get_state()
+                assert np.array_equal(al, orc.alive) and np.array_equal(p, orc.pos), (case_no, chunk, kw)
+                assert np.array_equal(sg, orc.spin) and np.array_equal(bd, orc.bound), (case_no, chunk, kw)
+                if chunk == 2:
+                    h.resort()
+            ex, ex0 = h.exits(), orc.exits()
+            assert len(ex) == len(ex0)
+            if len(ex0):
+                assert np.array_equal(ex, ex0[np.lexsort((ex0[:, 2], ex0[:, 0]))]), (case_no, kw)
+        finally:
+            h.close()

@@ -41,7 +41,7 @@ def _oracle_run(ctor, beta, seed, dt, T, obs_dt, stride):
     rng = np.random.default_rng(seed)
     pos = rng.choice(ctor["L"], size=ctor["N"], replace=False)
     spin = rng.choice([1, -1], size=ctor["N"]).astype(np.int8)
-    orc = so.SyncOracle(par, dt=dt, seed=int(rng.integers(0, 2 ** 63)))
+    orc = so.SyncOracle(par, dt=dt, seed=int(rng.random() * 2.0 ** 53))
     orc.set_state(pos, spin)
     times = np.arange(0.0, T, obs_dt)
     com, m_ts, done = [], [], 0
