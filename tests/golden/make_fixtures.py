@@ -426,25 +426,42 @@ def make_g7():
 
 
 # --------------------------------------------------------------------------------------- g6
+G6_CASES = [
+    dict(tag="periodic_bidirectional_local", bc="periodic", active_model="bidirectional", gaussian_kernel=False, init="poisson"),
+    dict(tag="neumann_anchored_kernel", bc="neumann", active_model="anchored_minus", gaussian_kernel=True, init="poisson"),
+    dict(tag="periodic_anchored_kernel", bc="periodic", active_model="anchored_minus", gaussian_kernel=True, init="homogeneous"),
+    dict(tag="neumann_bidirectional_local", bc="neumann", active_model="bidirectional", gaussian_kernel=False, init="homogeneous"),
+]
+G6_KW = dict(L=200, xlim=1.0, T=0.15, dt=5e-4, gamma=2.33e-4, lam=0.6, beta=2.0, kernel_sigma=0.02, snapshot_interval=100)
+
+
 def make_g6():
+    """Hydrodynamic-limit PDE (IMEX_PDE_solver_class.py:11-307): seeded short runs of all four
+    boundary-condition / active-model combinations, tracers included."""
+    import tempfile
     import IMEX_PDE_solver_class as ref_pde
     arrays, cases = {}, []
-    for c_idx, model in enumerate(("anchored_minus", "symmetric")):
-        kw = dict(L=200, T=1.0, dt=5e-4)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:       # the constructor creates an output directory in the cwd
+        os.chdir(tmp)
         try:
-            np.random.seed(600 + c_idx)
-            pde = ref_pde.IMEXPDE(active_model=model, **kw)
-        except TypeError as exc:           # constructor keywords differ; record and skip
-            print("  g6 skipped:", exc)
-            return
-        pde.initialize()
-        pde.solve()
-        o = pde.get_output()
-        for k, v in o.items():
-            if isinstance(v, np.ndarray):
-                arrays[f"c{c_idx}_{k}"] = v
-        cases.append(dict(model=model, kw=kw, seed=600 + c_idx))
-    _save("g6_pde.npz", dict(cases=cases), arrays)
+            for c_idx, c in enumerate(G6_CASES):
+                pde = ref_pde.IMEXPDE(bc=c["bc"], active_model=c["active_model"], gaussian_kernel=c["gaussian_kernel"],
+                                      seed=600 + c_idx, outdir="out", **G6_KW)
+                pde.initialize(mode=c["init"], rho0=1.0, noise=0.2, n_tracers=300)
+                arrays[f"c{c_idx}_rho_p0"], arrays[f"c{c_idx}_rho_m0"] = pde.rho_p.copy(), pde.rho_m.copy()
+                pde.solve()
+                o = pde.get_output()
+                for k in ("rho_p", "rho_m", "m_series", "var_series", "v_eff_series", "D_eff_series", "snapshots", "times"):
+                    arrays[f"c{c_idx}_{k}"] = np.asarray(o[k])
+                arrays[f"c{c_idx}_fft_amp_last"] = o["fft_amp"][-1]
+                arrays[f"c{c_idx}_tracers"] = pde.tracers_unwrapped.copy()
+                arrays[f"c{c_idx}_tracer_state"] = pde.tracer_state.copy()
+                cases.append(dict(c, seed=600 + c_idx))
+                print("  g6", c["tag"], "m_end", float(o["m_series"][-1]), "mass", float((o["rho_p"] + o["rho_m"]).sum()))
+        finally:
+            os.chdir(cwd)
+    _save("g6_pde.npz", dict(cases=cases, kw=G6_KW, init=dict(rho0=1.0, noise=0.2, n_tracers=300)), arrays)
 
 
 if __name__ == "__main__":
