@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (all-pairs sums -> rates -> Philox draw -> commit) over all N
-particles.  Workload: N=100000 particles on L=200000 sites, K=1, reflecting walls,
+A step = one pass of the hot path (mean field + occupancy at every particle -> rates -> Philox draw -> commit)
+over all N particles, in the formulation --method selects: "lattice" (default: the reference's histogram ->
+smoothing -> gather, the smoothed histograms kept incrementally on the L sites) or "pairs" (all-pairs tile kernel).  Workload: N=100000 particles on L=200000 sites, K=1, reflecting walls,
 sigma=0.005 (sigma_g=1000, 4001 taps), beta=0.7, rate_active=5, rate_diffusion=0.02, dt=0.0125,
 uniform-in-box synthetic initial condition, float64.  With --gpus N the particles are sharded by index
 (strong scaling of ONE system: the per-step all-gather carries 1 byte per particle).
@@ -32,18 +33,28 @@ EXTRA = {
     "config5": dict(WORK, N=1_000_000, L=2_000_000),                                          # f64 here (no f32 path)
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
+ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # SURVEY 8d (all-pairs): 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
+# Lattice formulation, algorithmic bytes per launch, N particles, L sites, C changed particles, D deposits:
+#   propose_lattice  N * (4 state + 4 index + 16 {W,S} + 12 occupancy + 1 proposal) + 4 L (site counters cleared)
+#   apply            N * (1 proposal + 4 state + 4 index) + C * (8 state/source word + 8 occupancy) + 4 D + 16 N / 64
+#   field_update     L * 32 ({W,S} read + write) + 4 D
+def lattice_algo_bytes(kernel, N, L, changed, deposits):
+    return {"propose_lattice": 37.0 * N + 4.0 * L,
+            "apply": 9.25 * N + 16.0 * changed + 4.0 * deposits,
+            "field_update": 32.0 * L + 4.0 * deposits}[kernel]
+
+
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
 LDS_CYCLES_PER_64_PAIRS = 5.0  # measured (PMC 4.93): 4.5 per table gather (2.0 + 2.5 bank conflicts) + 0.5 source broadcast
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 FETCH_SIZE/WRITE_SIZE of this command
 
 
-def measured_traffic_bytes():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py
+def measured_traffic_bytes(kernel="pair_accumulate"):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (bench.py
     cannot collect PMC itself).  None if the summary is missing."""
     try:
         with open(TRAFFIC_FILE) as fh:
-            d = json.load(fh)["per_dispatch"]["pair_accumulate"]
+            d = json.load(fh)["per_dispatch"][kernel]
         return (d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0
     except Exception:
         return None
@@ -56,10 +67,10 @@ def initial_state(w):
     return pos, spin
 
 
-def make_handle(capi, w, device=0, rank=0, world=1):
+def make_handle(capi, w, device=0, rank=0, world=1, method="auto"):
     return capi.Handle(L=w["L"], K=w["K"], periodic=False, sigma_grid=w["sigma"] / (w["xlim"] / w["L"]),
                        rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"], beta=w.get("betas", [w["beta"]]),
-                       dt=w["dt"], seed=w["seed"], n_particles=w["N"], device=device, rank=rank, world=world)
+                       dt=w["dt"], seed=w["seed"], n_particles=w["N"], device=device, rank=rank, world=world, method=method)
 
 
 def cpu_baseline(w, budget_s=12.0):
@@ -128,6 +139,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2"] + sorted(EXTRA))
+    ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs"])
     args = ap.parse_args()
     w = dict(WORK) if args.workload == "config2" else dict(EXTRA[args.workload])
     n_ens = len(w.get("betas", [0]))
@@ -146,7 +158,7 @@ def main():
         torch.cuda.set_device(local_rank)
         with stdout_to_stderr():                             # gloo announces its connections on stdout
             dist.init_process_group("gloo")                  # rendezvous / barriers only; the data path is RCCL below
-        h = make_handle(capi, w, device=local_rank, rank=rank, world=world)
+        h = make_handle(capi, w, device=local_rank, rank=rank, world=world, method=args.method)
         h.set_state(pos, spin)
         # preferred: the library all-gathers the proposal bytes itself (ncclAllGather on its stream, no Python per step)
         ok, path = 1, "in-library RCCL all-gather"
@@ -191,31 +203,59 @@ def main():
         assert bool((lo == hi).all()), "ranks diverged"
         comm_path = path
     else:
-        h = make_handle(capi, w)
+        h = make_handle(capi, w, method=args.method)
         for e in range(n_ens):
             h.set_state(pos, spin, ensemble=e)
         h.step(args.warmup)                       # aps_step synchronises its stream before returning
         t0 = time.perf_counter()
         h.step(args.steps)
         elapsed = time.perf_counter() - t0
-        # dominant kernel, timed live with HIP events on the stream it is launched on
+        # per-kernel durations, timed live with HIP events on the stream the kernels are launched on
         reps = max(10, min(args.steps, 50))
-        ms, launches, pairs = h.step_timed(reps)
-        avg_s = ms / launches * 1e-3
-        achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens / avg_s / 1e9
-        pairs_per_s = pairs / (ms * 1e-3)
-        lds_peak_pairs = 256 * 2.4e9 / LDS_CYCLES_PER_64_PAIRS * 64      # one LDS pipe per CU
-        roof = {"bound": "hbm", "kernel": "pair_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
-                "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens,
-                "note": "the contract's HBM figure; this kernel is bound by the LDS table gather (the 0.4 MB state "
-                        "lives in L2), see on_chip",
-                "on_chip": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs_per_s,
-                            "lds_bound_pairs_per_s": lds_peak_pairs, "lds_frac": pairs_per_s / lds_peak_pairs,
-                            "lds_cycles_per_64_pairs": LDS_CYCLES_PER_64_PAIRS,
-                            "valu_issue_slots_per_pair": 4, "valu_frac": pairs_per_s * 4 / VALU_LANE_OPS_PER_S}}
+        if h.method == "pairs":
+            ms, launches, pairs = h.step_timed(reps)
+            avg_s = ms / launches * 1e-3
+            achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens / avg_s / 1e9
+            pairs_per_s = pairs / (ms * 1e-3)
+            lds_peak_pairs = 256 * 2.4e9 / LDS_CYCLES_PER_64_PAIRS * 64      # one LDS pipe per CU
+            roof = {"bound": "hbm", "kernel": "pair_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
+                    "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens,
+                    "note": "the contract's HBM figure; this kernel is bound by the LDS table gather (the 0.4 MB state "
+                            "lives in L2), see on_chip",
+                    "on_chip": {"pairs_per_launch": pairs / launches, "pairs_per_s": pairs_per_s,
+                                "lds_bound_pairs_per_s": lds_peak_pairs, "lds_frac": pairs_per_s / lds_peak_pairs,
+                                "lds_cycles_per_64_pairs": LDS_CYCLES_PER_64_PAIRS,
+                                "valu_issue_slots_per_pair": 4, "valu_frac": pairs_per_s * 4 / VALU_LANE_OPS_PER_S}}
+        else:
+            before = h.get_state()
+            ms_fu, n_fu, deposits = h.step_timed(reps)            # deposits = field changes of the sampled steps
+            after = h.get_state()
+            prof = h.step_profile(reps)
+            kern = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}          # seconds per launch
+            dep_per_step = deposits / max(n_fu, 1)
+            changed_per_step = 0.6 * dep_per_step                 # a hop makes 2 deposits, a flip 1 (about half each)
+            N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
+            algo = {k: lattice_algo_bytes(k, N_all, L_all, changed_per_step, dep_per_step) for k in kern}
+            dom = max(kern, key=kern.get)
+            achieved = algo[dom] / kern[dom] / 1e9
+            step_bytes = sum(algo.values())
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(dom),
+                    "avg_launch_us": kern[dom] * 1e6, "algorithmic_bytes_per_launch": algo[dom],
+                    "per_kernel": {k: {"avg_launch_us": kern[k] * 1e6, "algorithmic_bytes_per_launch": algo[k],
+                                       "achieved_GBps": algo[k] / kern[k] / 1e9, "traffic": measured_traffic_bytes(k)} for k in kern},
+                    "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step_graph_replay": elapsed / args.steps * 1e6,
+                                   "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
+                                   "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                    "deposits_per_step": dep_per_step,
+                    "note": "lattice formulation: three short kernels per step replayed from a hipGraph; the per-kernel "
+                            "durations come from an event-bracketed run launched kernel by kernel; the working set (12 MB) "
+                            "is cache resident, so the kernels are latency / launch-boundary bound, not HBM bound"}
+            del before, after
     p, s, b, a = h.get_state()
     assert a.all() and np.bincount(p, minlength=w["L"]).max() <= w["K"]
+    h_method = h.method
     h.close()
     if rank != 0:
         return
@@ -226,6 +266,7 @@ def main():
         "config": {"workload": ("BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
                                 "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on") if args.workload == "config2"
                                else f"BASELINE {args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma=0.005, dt=0.0125",
+                   "method": h_method,
                    "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"
                                + (f" ({comm_path})" if sharded_path else "")},
     }

@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(HERE, "libaps_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "aps.h")
 
 APS_OK, APS_ERR_ARG, APS_ERR_HIP, APS_ERR_STATE, APS_ERR_NODEVICE = 0, -1, -2, -3, -4
+METHODS = {"auto": 0, "pairs": 1, "lattice": 2}          # APS_METHOD_* of include/aps.h
+KERNELS = ("pair_accumulate", "propose", "claim", "apply", "plan_tiles", "propose_lattice", "field_update")
 
 
 class ApsError(RuntimeError):
@@ -36,7 +38,7 @@ class ApsParams(C.Structure):
         ("k_off", C.c_double), ("k_exit", C.c_double), ("dt", C.c_double), ("seed", C.c_uint64),
         ("beta", C.POINTER(C.c_double)), ("anchor_mask", C.POINTER(C.c_uint8)), ("device", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("sort_by_site", C.c_int32),
-        ("ensemble_base", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("ensemble_base", C.c_int32), ("method", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -98,6 +100,10 @@ def load():
         "aps_get_table": (C.c_int, [vp, vp, i32, P(i32), P(i32)]),
         "aps_resort": (C.c_int, [vp]),
         "aps_step_timed": (C.c_int, [vp, i64, P(dbl), P(i64), P(dbl)]),
+        "aps_step_profile": (C.c_int, [vp, i64, vp, vp]),
+        "aps_lattice_accumulate": (C.c_int, [vp, i32, vp, vp, vp, i64]),
+        "aps_get_lattice": (C.c_int, [vp, i32, vp, vp, vp]),
+        "aps_method": (C.c_int, [vp]),
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
@@ -120,7 +126,7 @@ class Handle:
     def __init__(self, *, L, K, periodic, sigma_grid, rate_diffusion, rate_active, beta, dt, seed,
                  n_particles, minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False,
                  k_on=0.0, k_off=0.0, k_exit=0.0, anchor_mask=None, device=0, rank=0, world=1,
-                 sort_by_site=True, ensemble_base=0):
+                 sort_by_site=True, ensemble_base=0, method="auto"):
         self.lib = load()
         self._h = C.c_void_p()
         betas = np.atleast_1d(np.asarray(beta, dtype=np.float64)).copy()
@@ -138,10 +144,11 @@ class Handle:
                         beta=betas.ctypes.data_as(C.POINTER(C.c_double)),
                         anchor_mask=None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_uint8)),
                         device=int(device), rank=int(rank), world=int(world),
-                        sort_by_site=int(bool(sort_by_site)), ensemble_base=int(ensemble_base))
+                        sort_by_site=int(bool(sort_by_site)), ensemble_base=int(ensemble_base), method=METHODS[method])
         rc = self.lib.aps_create(C.byref(par), C.byref(self._h))
         if rc != APS_OK:
             raise ApsError(rc, self.lib.aps_last_error(None).decode())
+        self.method = {1: "pairs", 2: "lattice"}[self.lib.aps_method(self._h)]
 
     # -- plumbing
     def _ck(self, rc):
@@ -185,6 +192,19 @@ class Handle:
         self._ck(self.lib.aps_pair_accumulate(self._h, ensemble, _ptr(S), _ptr(W), _ptr(occ4), n))
         return S, W, occ4
 
+    def lattice_accumulate(self, ensemble=0):
+        """S, W, occ4 per particle read from the maintained lattice arrays (lattice formulation only)."""
+        n = self._n_set[ensemble]
+        S, W, occ4 = np.zeros(n), np.zeros(n), np.zeros((n, 4), np.int32)
+        self._ck(self.lib.aps_lattice_accumulate(self._h, ensemble, _ptr(S), _ptr(W), _ptr(occ4), n))
+        return S, W, occ4
+
+    def get_lattice(self, ensemble=0):
+        """The maintained lattice arrays: W = tot_conv, S = s_conv (weight-grid units), occ = particles per site."""
+        W, S, occ = np.zeros(self.L), np.zeros(self.L), np.zeros(self.L, np.int32)
+        self._ck(self.lib.aps_get_lattice(self._h, ensemble, _ptr(W), _ptr(S), _ptr(occ)))
+        return W, S, occ
+
     # -- stepping
     def step(self, nsteps=1):
         self._ck(self.lib.aps_step(self._h, int(nsteps)))
@@ -211,6 +231,12 @@ class Handle:
         ms, n, pairs = C.c_double(), C.c_int64(), C.c_double()
         self._ck(self.lib.aps_step_timed(self._h, int(nsteps), C.byref(ms), C.byref(n), C.byref(pairs)))
         return ms.value, n.value, pairs.value
+
+    def step_profile(self, nsteps):
+        """{kernel: (summed ms, launches)} over nsteps steps launched one by one with HIP events around each."""
+        ms, cnt = np.zeros(len(KERNELS)), np.zeros(len(KERNELS), np.int64)
+        self._ck(self.lib.aps_step_profile(self._h, int(nsteps), _ptr(ms), _ptr(cnt)))
+        return {k: (float(m), int(c)) for k, m, c in zip(KERNELS, ms, cnt)}
 
     # -- observation
     def observe(self, ensemble=0, want_field=True):

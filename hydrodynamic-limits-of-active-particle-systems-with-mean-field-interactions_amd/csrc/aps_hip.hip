@@ -429,6 +429,39 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
     return c;
 }
 
+// Epilogue shared by both formulations: m = clip(S/W) -> rates (ref :261-351) -> Philox draw -> proposal byte
+// (event code | (free capacity of the hop target - 1) << 3).  c0/cl/cr = occupancy of the own / left / right site.
+__device__ inline uint8_t draw_proposal(const Model &M, bool anch, int p, int spin, bool bound, double accS, double accW,
+                                        double beta, int c0, int cl, int cr, uint32_t step_lo, uint32_t step_hi,
+                                        uint32_t orig, int ens) {
+    double mloc = 0.0;
+    if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+    const Channels c = channels(M, anch, p, spin, bound, mloc, beta, c0, cl, cr);
+    uint32_t x[4];
+    philox4x32_10(step_lo, step_hi, orig, (uint32_t)ens, M.seed_lo, M.seed_hi, x);
+    const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
+    const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
+    const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
+    if (!(u0 < p_fire)) return EV_NONE;
+    const double v = u1 * c.total;
+    const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
+                 e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
+    int ev = EV_NONE, occ_t = 0;
+    if (v < e_diff) {
+        if (c.left + c.right > 0.0) {
+            if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
+            else { ev = EV_RIGHT; occ_t = cr; }
+        }
+    } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
+    else if (v < e_bind) ev = EV_BIND;
+    else if (v < e_unbind) ev = EV_UNBIND;
+    else if (v < e_exit) ev = EV_EXIT;
+    else ev = EV_FLIP;
+    int cap = M.K - occ_t;                                   // free capacity of the hop target at step start
+    cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
+    return (uint8_t)(ev | ((cap - 1) << 3));
+}
+
 // plan<BC>: one wave per target group (RT consecutive tiles) lists the source tiles that can matter (tile index
 // | loop variant << 28) into plan[e][group][0..PLAN_CAP) and their number into plan_n[e][group] (a count >
 // PLAN_CAP means "scan in-kernel").
@@ -598,36 +631,9 @@ __global__ __launch_bounds__(256) void propose(const PairArgs a) {
     }
     if (!a.write_prop) return;
     uint8_t code = EV_NONE;
-    if (live) {
-        double mloc = 0.0;
-        if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
-        const bool anch = a.anchor ? a.anchor[p] != 0 : false;
-        const Channels c = channels(M, anch, p, spin, bound, mloc, a.beta[e], c0, cl, cr);
-        uint32_t x[4];
-        philox4x32_10(a.step_lo, a.step_hi, a.orig[o], (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, x);
-        const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
-        const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
-        const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
-        if (u0 < p_fire) {
-            const double v = u1 * c.total;
-            const double e_diff = c.diff, e_act = e_diff + c.act, e_bind = e_act + c.bind,
-                         e_unbind = e_bind + c.unbind, e_exit = e_unbind + c.leave;
-            int ev = EV_NONE, occ_t = 0;
-            if (v < e_diff) {
-                if (c.left + c.right > 0.0) {
-                    if (u2 < c.left / (c.left + c.right)) { ev = EV_LEFT; occ_t = cl; }
-                    else { ev = EV_RIGHT; occ_t = cr; }
-                }
-            } else if (v < e_act) { ev = EV_FWD; occ_t = cr; }
-            else if (v < e_bind) ev = EV_BIND;
-            else if (v < e_unbind) ev = EV_UNBIND;
-            else if (v < e_exit) ev = EV_EXIT;
-            else ev = EV_FLIP;
-            int cap = M.K - occ_t;                           // free capacity of the hop target at step start
-            cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
-            code = (uint8_t)(ev | ((cap - 1) << 3));
-        }
-    }
+    if (live)
+        code = draw_proposal(M, a.anchor ? a.anchor[p] != 0 : false, p, spin, bound, accS, accW, a.beta[e], c0, cl, cr,
+                             a.step_lo, a.step_hi, a.orig[o], M.ens_base + e);
     const int r = (int)(slot / a.SH);
     a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
     if (a.fuse_claim) {                                       // same as claim(): join the target site's proposer list
@@ -651,7 +657,20 @@ struct CommitArgs {
     double *exit_log; unsigned *n_exit; int exit_cap;
     int Npad, SH, E, ntiles, parity;
     double step_as_double;
+    // lattice formulation (all null / 0 in the all-pairs formulation)
+    const unsigned long long *stepw;     // device step words: the step index is stepw[parity] (graph replays)
+    uint32_t *occ_site;                  // [E][L] particles per site
+    uint32_t *dcnt, *dep;                // [E][nb] deposit counters, [E][nb][dcap] deposits of this step
+    int bshift, nb, dcap;
 };
+
+// A deposit = one change of the lattice field caused by an accepted event: add cW * w(x - site) to W(x) and
+// cS * w(x - site) to S(x) for every site x in reach.  hop of a spin-s particle: (-1, -s) at the old site and
+// (+1, +s) at the new one; flip s -> -s: (0, -2s); exit: (-1, -s).  Packed: site | (cW + 1) << 27 | (cS + 2) << 29.
+__device__ __host__ inline uint32_t deposit(int site, int cw, int cs) {
+    return (uint32_t)site | ((uint32_t)(cw + 1) << 27) | ((uint32_t)(cs + 2) << 29);
+}
+constexpr uint32_t DEP_NULL = (1u << 27) | (2u << 29);        // cW = cS = 0: contributes nothing
 
 __device__ inline int hop_target(const Model &M, int p, int ev) {
     int s = (ev == EV_LEFT) ? p - 1 : p + 1;
@@ -684,25 +703,45 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
     const uint32_t my_orig = a.orig[(size_t)e * a.Npad + slot];
     int p = (int)(me & POS_MASK);
     if (!(me & DEAD_BIT)) {
+        const int p_old = p, sgn = (me & SPIN_BIT) ? 1 : -1;
+        uint32_t d0 = 0, d1 = 0;                              // lattice deposits of this particle
+        int nd = 0;
         if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
             const int s = hop_target(a.m, p, ev);
             const size_t site = (size_t)e * a.m.L + s;
             const uint32_t n = min(a.pcnt[(size_t)a.parity * a.E * a.m.L + site], 2u * a.m.K);
             int rank = 0;                                     // proposers to s with a smaller particle index
             for (uint32_t k = 0; k < n; ++k) rank += a.plist[site * 2 * a.m.K + k] < my_orig;
-            if (rank < (code >> 3) + 1) { p = s; me = (me & ~POS_MASK) | (uint32_t)s; }
+            if (rank < (code >> 3) + 1) {
+                p = s; me = (me & ~POS_MASK) | (uint32_t)s;
+                if (a.occ_site) {
+                    atomicAdd(&a.occ_site[site], 1u);
+                    atomicSub(&a.occ_site[(size_t)e * a.m.L + p_old], 1u);
+                    d0 = deposit(p_old, -1, -sgn); d1 = deposit(s, 1, sgn); nd = 2;
+                }
+            }
         } else if (ev == EV_BIND) me |= BOUND_BIT;
         else if (ev == EV_UNBIND) me &= ~BOUND_BIT;
-        else if (ev == EV_FLIP) me ^= SPIN_BIT;
+        else if (ev == EV_FLIP) { me ^= SPIN_BIT; d0 = deposit(p, 0, -2 * sgn); nd = 1; }
         else if (ev == EV_EXIT) {
             me |= DEAD_BIT;
             const unsigned k = atomicAdd(&a.n_exit[e], 1u);
             if ((int)k < a.exit_cap) {
                 double *row = a.exit_log + ((size_t)e * a.exit_cap + k) * 3;
-                row[0] = a.step_as_double; row[1] = (double)p; row[2] = (double)my_orig;
+                row[0] = a.stepw ? (double)a.stepw[a.parity] : a.step_as_double; row[1] = (double)p; row[2] = (double)my_orig;
             }
+            if (a.occ_site) atomicSub(&a.occ_site[(size_t)e * a.m.L + p], 1u);
+            d0 = deposit(p, -1, -sgn); nd = 1;
         }
         if (ev != EV_NONE) a.src[(size_t)e * a.Npad + slot] = me;
+        if (a.dep && nd) {                                    // binned by the OLD site: <= 2 per particle, so a bucket
+            const size_t b = (size_t)e * a.nb + (size_t)(p_old >> a.bshift);   // of B sites never exceeds 2 K B
+            const uint32_t k = atomicAdd(&a.dcnt[b], (uint32_t)nd);
+            if (k + (uint32_t)nd <= (uint32_t)a.dcap) {
+                a.dep[b * a.dcap + k] = d0;
+                if (nd == 2) a.dep[b * a.dcap + k + 1] = d1;
+            }
+        }
     }
     // pre-decoded source pair for the next all-pairs pass, per-tile (= per-wave) info, global spin sums
     const bool live = !(me & DEAD_BIT);
@@ -719,6 +758,219 @@ __global__ __launch_bounds__(256) void apply(const CommitArgs a) {
         if (a.m.field_mode == 0 && cnt) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e]), (unsigned long long)(long long)ssum);
             atomicAdd(reinterpret_cast<unsigned long long *>(&a.gsum[2 * e + 1]), (unsigned long long)cnt);
+        }
+    }
+}
+
+// ================================================================================ lattice formulation
+// The reference's own algorithm (histogram -> Gaussian smoothing -> read back at the particle sites, ref
+// :216-246, :261-301), kept INCREMENTALLY: the smoothed histograms W(x) = tot_conv, S(x) = s_conv live on the L
+// sites and every accepted event adds its change (a "deposit") to the sites in reach.  All values sit on the
+// weight grid 2^-q, so add/subtract sequences are exact and W, S equal a from-scratch recomputation bit for
+// bit after any number of steps (tests compare with the oracle's recomputation and with the all-pairs kernel).
+// Per step:  propose_lattice (gather W,S,occupancy at the particle -> rates -> Philox -> proposal)
+//            [all-gather + claim when sharded]  apply (commit; occupancy and deposits)  field_update.
+struct LatticeArgs {
+    Model m;
+    const uint32_t *src, *orig;
+    const double2 *ws;                   // [E][L] {W, S}
+    const uint32_t *occ_site;            // [E][L]
+    const long long *gsum; long long *gsum_next;
+    const double *beta; const uint8_t *anchor;
+    uint8_t *prop; uint32_t *pcnt, *plist, *dcnt;
+    unsigned long long *stepw;           // [2]: step n reads stepw[n & 1] and writes n + 1 to the other word
+    double *S_out, *W_out; int *occ4_out;
+    int par, fuse_claim, write_prop, Npad, SH, E, tile_lo, tile_cnt, nb;
+};
+
+__global__ __launch_bounds__(256) void propose_lattice(const LatticeArgs a) {
+    const Model &M = a.m;
+    const int e = blockIdx.y;
+    const unsigned long long step = a.stepw[a.par];
+    if (a.write_prop) {   // idle buffers of the coming commit: the other parity's site counters, the deposit counters
+        uint32_t *other = a.pcnt + ((size_t)(a.par ^ 1) * a.E + e) * M.L;
+        const size_t nthreads = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (size_t i = t0; i < (size_t)M.L; i += nthreads) other[i] = 0u;
+        if (a.dcnt) for (size_t i = t0; i < (size_t)a.nb; i += nthreads) a.dcnt[(size_t)e * a.nb + i] = 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.gsum_next[2 * e] = 0; a.gsum_next[2 * e + 1] = 0;
+            if (e == 0) a.stepw[a.par ^ 1] = step + 1ull;     // nobody reads that word during this step
+        }
+    }
+    const size_t slot = (size_t)a.tile_lo * TILE + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (size_t)(a.tile_lo + a.tile_cnt) * TILE) return;
+    const size_t o = (size_t)e * a.Npad + slot;
+    const uint32_t me = a.src[o];
+    const bool live = !(me & DEAD_BIT);
+    const int p = (int)(me & POS_MASK), L = M.L;
+    const int spin = (me & SPIN_BIT) ? 1 : -1;
+    const bool bound = (me & BOUND_BIT) != 0;
+    double accW = 0.0, accS = 0.0;
+    int c0 = 0, cl = 0, cr = 0;
+    if (live) {
+        const uint32_t *occ = a.occ_site + (size_t)e * L;
+        int l = p - 1, r = p + 1;
+        if (M.periodic) { l = l < 0 ? l + L : l; r = r >= L ? r - L : r; }
+        c0 = (int)occ[p];
+        cl = l >= 0 ? (int)occ[l] : 0;
+        cr = r < L ? (int)occ[r] : 0;
+        if (M.field_mode == 0) { accS = (double)a.gsum[2 * e]; accW = (double)a.gsum[2 * e + 1]; }
+        else { const double2 f = a.ws[(size_t)e * L + p]; accW = f.x; accS = f.y; }
+    }
+    const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == L - 1;
+    if (a.S_out) {
+        a.S_out[o] = accS;
+        a.W_out[o] = accW;
+        int *oo = a.occ4_out + o * 4;
+        const int o_l = wall_l ? c0 : cl, o_r = wall_r ? c0 : cr;
+        oo[0] = c0; oo[1] = live ? (spin > 0 ? o_r : c0) : 0; oo[2] = live ? o_l : 0; oo[3] = live ? o_r : 0;
+    }
+    if (!a.write_prop) return;
+    uint8_t code = EV_NONE;
+    if (live)
+        code = draw_proposal(M, a.anchor ? a.anchor[p] != 0 : false, p, spin, bound, accS, accW, a.beta[e], c0, cl, cr,
+                             (uint32_t)step, (uint32_t)(step >> 32), a.orig[o], M.ens_base + e);
+    const int r = (int)(slot / a.SH);
+    a.prop[((size_t)r * a.E + e) * a.SH + (slot - (size_t)r * a.SH)] = code;
+    if (a.fuse_claim) {                                       // same as claim(): join the target site's proposer list
+        const int ev = code & 7;
+        if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
+            int s = (ev == EV_LEFT) ? p - 1 : p + 1;
+            if (M.periodic) s = s < 0 ? s + L : (s >= L ? s - L : s);
+            const size_t site = (size_t)e * L + s;
+            const uint32_t k = atomicAdd(&a.pcnt[(size_t)a.par * a.E * L + site], 1u);
+            if (k < 2u * M.K) a.plist[site * 2 * M.K + k] = a.orig[o];
+        }
+    }
+}
+
+// field_update: one workgroup owns 256 * R consecutive sites (lane = R sites, 256 apart) and adds every deposit
+// in reach to them.  The deposits sit in per-bucket lists (bucket = B consecutive sites of the depositing
+// particle's old position); the workgroup copies the lists of the buckets in reach into LDS (counts -> scan ->
+// copy, 8 threads per bucket) and all waves then sweep that list: the deposit is wave-uniform (scalar
+// registers), so the 64 lanes read 64 CONSECUTIVE table entries -- a conflict-free ds_read_b64 -- and issue two
+// f64 fma's (W and S).  Nobody else writes these sites: plain read-modify-write at the end, no atomics.
+constexpr int FU_THREADS = 256, FU_LIST = 2048;
+struct FieldUpdArgs { int L, tlen, bshift, nb, dcap; double2 *ws; const uint32_t *dcnt, *dep; };
+
+__host__ __device__ inline size_t fu_lds_bytes(int tlen, bool tab_lds) {
+    return lds_table_bytes(tlen, tab_lds) + (size_t)(FU_LIST + 4 + 256 + 256 + 8) * sizeof(uint32_t);
+}
+
+template <int VAR, bool TAB_LDS, int R>   // VAR: 0 = interior (no image term), 1 = torus, 2 = reflecting wall in reach
+__device__ __forceinline__ void fu_entry(const uint32_t ent_v, const uint32_t (&x8)[R], const uint32_t tbase, const double *__restrict__ table_g,
+                                         const uint32_t tlen8, const uint32_t L8, double (&accW)[R], double (&accS)[R]) {
+    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent_v);      // wave-uniform: decode on the scalar unit
+    const uint32_t p8 = (ent & POS_MASK) << 3;
+    const double cw = (double)((int)((ent >> 27) & 3u) - 1), cs = (double)((int)(ent >> 29) - 2);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double w;
+        if (VAR == 0) {
+            w = table_at<TAB_LDS>(table_g, min(sad3(x8[r], p8, tbase), tlen8 + tbase));
+        } else if (VAR == 1) {
+            const uint32_t d8 = sad3(x8[r], p8, 0u);
+            w = table_at<TAB_LDS>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
+        } else {
+            const uint32_t s8 = x8[r] + p8 + 8u;
+            w = table_at<TAB_LDS>(table_g, min(sad3(x8[r], p8, 0u), tlen8) + tbase);
+            w += table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
+        }
+        accW[r] = fma(w, cw, accW[r]);                       // cw, cs in {-2..2}: exact on the weight grid
+        accS[r] = fma(w, cs, accS[r]);
+    }
+}
+
+template <int BC, bool TAB_LDS, int R>
+__global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a, const double *__restrict__ table_g) {
+    extern __shared__ double lds[];
+    uint32_t *list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + lds_table_bytes(a.tlen, TAB_LDS));
+    uint32_t *bc = list + FU_LIST + 4, *bo = bc + 256, *wtot = bo + 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, e = blockIdx.y;
+    const int L = a.L, x0 = blockIdx.x * FU_THREADS * R, x1 = min(x0 + FU_THREADS * R - 1, L - 1);
+    const int Rt = a.tlen - 1;                                // largest distance with a non-zero weight
+    // buckets whose deposits can reach [x0, x1]: deposit sites lie within one site of their bucket
+    int rlo[2], rhi[2], nr = 1;
+    if (BC == 0) {
+        rlo[0] = max(0, x0 - Rt - 1) >> a.bshift; rhi[0] = min(L - 1, x1 + Rt + 1) >> a.bshift;
+    } else {
+        const int lo = x0 - Rt - 1, hi = x1 + Rt + 1;
+        if (hi - lo + 1 >= L) { rlo[0] = 0; rhi[0] = a.nb - 1; }
+        else if (lo >= 0 && hi < L) { rlo[0] = lo >> a.bshift; rhi[0] = hi >> a.bshift; }
+        else {
+            const int h1 = lo < 0 ? hi : hi - L, l2 = lo < 0 ? lo + L : lo;     // [0, h1] and [l2, L-1]
+            rlo[0] = 0; rhi[0] = h1 >> a.bshift; rlo[1] = l2 >> a.bshift; rhi[1] = a.nb - 1; nr = 2;
+            if (rlo[1] <= rhi[0]) { rhi[0] = a.nb - 1; nr = 1; }
+        }
+    }
+    const bool wall = BC == 0 && ((x0 + 1 <= Rt) || (L - x1 <= Rt));   // an image term can be non-zero
+    uint32_t tbase = 0;
+    if (TAB_LDS) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        tbase = (uint32_t)(size_t)(lds_double *)lds;
+    }
+    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)L << 3;
+    uint32_t x8[R];
+    double accW[R], accS[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { x8[r] = (uint32_t)min(x0 + r * FU_THREADS + t, L - 1) << 3; accW[r] = accS[r] = 0.0; }
+    bool staged = false, touched = false;
+    for (int ri = 0; ri < nr; ++ri)
+        for (int cb = rlo[ri]; cb <= rhi[ri]; cb += 256) {
+            const int nbk = min(256, rhi[ri] - cb + 1);
+            const uint32_t c = t < nbk ? min(a.dcnt[(size_t)e * a.nb + cb + t], (uint32_t)a.dcap) : 0u;
+            uint32_t v = c;                                   // inclusive scan over the workgroup
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t n = __shfl_up(v, off); if (lane >= off) v += n; }
+            if (lane == 63) wtot[wave] = v;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < FU_THREADS / 64; ++w) { const uint32_t s = wtot[w]; total += s; if (w < wave) before += s; }
+            bc[t] = c; bo[t] = before + v - c;
+            __syncthreads();
+            if (total == 0) continue;                         // uniform
+            touched = true;
+            if (TAB_LDS && !staged) { stage_table(lds, table_g, a.tlen); staged = true; }
+            for (uint32_t w0 = 0; w0 < total; w0 += FU_LIST) {
+                const uint32_t wn = min((uint32_t)FU_LIST, total - w0);
+                for (int bi = t >> 3; bi < nbk; bi += FU_THREADS / 8) {       // 8 threads copy one bucket's list
+                    const uint32_t cnt = bc[bi], off = bo[bi];
+                    const uint32_t *from = a.dep + ((size_t)e * a.nb + cb + bi) * a.dcap;
+                    for (uint32_t k = t & 7; k < cnt; k += 8) {
+                        const uint32_t pos = off + k - w0;    // unsigned: entries before the window wrap to huge
+                        if (pos < wn) list[pos] = from[k];
+                    }
+                }
+                if (t < 4) list[wn + t] = DEP_NULL;           // pad to whole groups of four
+                __syncthreads();
+                const uint4 *list4 = reinterpret_cast<const uint4 *>(list);
+                const int n4 = (int)((wn + 3) >> 2);
+#pragma unroll 1
+                for (int i = 0; i < n4; ++i) {
+                    const uint4 q = list4[i];                 // uniform address: LDS broadcast
+                    if (BC == 1) {
+                        fu_entry<1, TAB_LDS, R>(q.x, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<1, TAB_LDS, R>(q.y, x8, tbase, table_g, tlen8, L8, accW, accS);
+                        fu_entry<1, TAB_LDS, R>(q.z, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<1, TAB_LDS, R>(q.w, x8, tbase, table_g, tlen8, L8, accW, accS);
+                    } else if (wall) {
+                        fu_entry<2, TAB_LDS, R>(q.x, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<2, TAB_LDS, R>(q.y, x8, tbase, table_g, tlen8, L8, accW, accS);
+                        fu_entry<2, TAB_LDS, R>(q.z, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<2, TAB_LDS, R>(q.w, x8, tbase, table_g, tlen8, L8, accW, accS);
+                    } else {
+                        fu_entry<0, TAB_LDS, R>(q.x, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<0, TAB_LDS, R>(q.y, x8, tbase, table_g, tlen8, L8, accW, accS);
+                        fu_entry<0, TAB_LDS, R>(q.z, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<0, TAB_LDS, R>(q.w, x8, tbase, table_g, tlen8, L8, accW, accS);
+                    }
+                }
+                __syncthreads();                              // the list is rewritten by the next window / chunk
+            }
+        }
+    if (!touched) return;                                     // nothing in reach (uniform)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int x = x0 + r * FU_THREADS + t;
+        if (x < L) {
+            double2 f = a.ws[(size_t)e * L + x];
+            f.x += accW[r]; f.y += accS[r];
+            a.ws[(size_t)e * L + x] = f;
         }
     }
 }
@@ -749,6 +1001,7 @@ __global__ __launch_bounds__(256) void rates_kernel(const RatesArgs a) {
 struct FieldArgs {
     Model m; const long long *gsum;
     double *m_out; int tlen, ntiles, e;
+    double2 *ws_out;          // optional [L]: the raw sums {W, S} (from-scratch build of the lattice field)
 };
 
 template <int BC, bool TAB_LDS>
@@ -779,6 +1032,8 @@ __global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const
                                     table_g, a.tlen, M.L, accWv, accSv, cnt);
     double accW = accWv[0], accS = accSv[0];
     if (x >= M.L) return;
+    if (a.ws_out) a.ws_out[x] = make_double2(accW, accS);
+    if (!a.m_out) return;
     if (M.field_mode == 0) { accS = (double)a.gsum[2 * a.e]; accW = (double)a.gsum[2 * a.e + 1]; }
     double mloc = 0.0;
     if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
@@ -824,6 +1079,21 @@ struct aps_handle {
     std::vector<int64_t> n_set;    // particles uploaded per ensemble
     std::vector<hipEvent_t> events;
     ncclComm_t comm = nullptr;     // set by aps_comm_init: aps_step then all-gathers the proposals itself
+    // lattice formulation
+    int method = APS_METHOD_PAIRS;
+    double2 *d_ws = nullptr;                   // [E][L] {W, S}
+    uint32_t *d_occ_site = nullptr;            // [E][L]
+    uint32_t *d_dcnt = nullptr, *d_dep = nullptr;
+    unsigned long long *d_stepw = nullptr;     // [2] device step words
+    int bshift = 8, nb = 0, dcap = 0, fu_R = 1;
+    bool field_dirty = true;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int graph_steps = 0;
+    // per-kernel timing (aps_step_timed / aps_step_profile): an event before every launch, kind of that launch
+    bool profiling = false;
+    std::vector<int> prof_kind;
+    size_t prof_n = 0;
     std::string err;
 };
 
@@ -999,10 +1269,13 @@ PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
     return a;
 }
 
+int prof_mark(aps_handle *h, int kind);
+
 int launch_plan(aps_handle *h, int first_tile, int tile_cnt) {
     PlanArgs pa{h->p.L, h->tlen, (int)h->ntiles, first_tile, tile_cnt, h->plan_interval > 1 ? 2 * h->plan_interval : 0,
                 h->d_plan, h->d_plan_n};
     h->plan_age = 0;
+    { int rc = prof_mark(h, 4 /* KIND_PLAN */); if (rc) return rc; }
     const dim3 grid((unsigned)((tile_cnt / RT + 3) / 4), (unsigned)h->E), block(256);
     if (h->p.periodic) hipLaunchKernelGGL(plan_tiles<1>, grid, block, 0, h->stream, pa, h->d_tinfo);
     else hipLaunchKernelGGL(plan_tiles<0>, grid, block, 0, h->stream, pa, h->d_tinfo);
@@ -1010,7 +1283,9 @@ int launch_plan(aps_handle *h, int first_tile, int tile_cnt) {
     return APS_OK;
 }
 
-int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+int prof_mark(aps_handle *h, int kind);
+
+int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) {
     PairArgs b = a;
     b.tile_lo = first_tile; b.tile_cnt = tile_cnt;
     const int shard_lo = (int)(h->rank * h->SH / TILE), shard_cnt = (int)(h->SH / TILE);
@@ -1034,12 +1309,12 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt, 
     const unsigned items = (unsigned)(tile_cnt / RT) * (unsigned)h->E * (unsigned)split;
     const dim3 grid(std::max(1u, std::min((items + WAVES - 1) / WAVES, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
-    if (ev0) HIP_TRY(h, hipEventRecord(ev0, h->stream));      // events bracket the dominant kernel alone
+    { int rc = prof_mark(h, 0 /* KIND_PAIR */); if (rc) return rc; }   // events bracket the dominant kernel alone
 #define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_accumulate<BC, TL>), grid, block, lds, h->stream, b, h->d_sp8, h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
-    if (ev1) HIP_TRY(h, hipEventRecord(ev1, h->stream));
+    { int rc = prof_mark(h, 1 /* KIND_PROPOSE */); if (rc) return rc; }
     const dim3 pgrid((unsigned)((tile_cnt * TILE + 255) / 256), (unsigned)h->E);
     hipLaunchKernelGGL(propose, pgrid, dim3(256), 0, h->stream, b);
     HIP_TRY(h, hipGetLastError());
@@ -1054,6 +1329,11 @@ CommitArgs commit_args(aps_handle *h) {
     c.plist = h->d_plist; c.gsum = h->d_gsum + (size_t)(c.parity ^ 1) * 2 * h->E; c.exit_log = h->d_exit;
     c.n_exit = h->d_nexit; c.exit_cap = h->exit_cap; c.Npad = (int)h->Npad; c.SH = (int)h->SH; c.E = h->E;
     c.ntiles = (int)h->ntiles; c.step_as_double = (double)h->step;
+    if (h->method == APS_METHOD_LATTICE) {
+        c.stepw = h->d_stepw; c.occ_site = h->d_occ_site;
+        if (h->model.field_mode) { c.dcnt = h->d_dcnt; c.dep = h->d_dep; }
+        c.bshift = h->bshift; c.nb = h->nb; c.dcap = h->dcap;
+    }
     return c;
 }
 
@@ -1066,6 +1346,12 @@ int set_lds_limit(aps_handle *h) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_accumulate<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
+    }
+    if (h->table_in_lds && fu_lds_bytes(h->tlen, true) > 48 * 1024) {
+        const int n = (int)fu_lds_bytes(h->tlen, true);
+#define APS_ATTR(BC, RR) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_update<BC, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, n))
+        APS_ATTR(0, 1); APS_ATTR(0, 2); APS_ATTR(0, 4); APS_ATTR(1, 1); APS_ATTR(1, 2); APS_ATTR(1, 4);
+#undef APS_ATTR
     }
     hipDeviceProp_t prop;
     HIP_TRY(h, hipGetDeviceProperties(&prop, h->p.device));
@@ -1083,9 +1369,9 @@ int set_lds_limit(aps_handle *h) {
     return APS_OK;
 }
 
-int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, int ntiles, double *m_out) {
+int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, int ntiles, double *m_out, double2 *ws_out = nullptr) {
     FieldArgs f{};
-    f.m = h->model; f.gsum = h->d_gsum + (size_t)(h->step & 1) * 2 * h->E; f.m_out = m_out;
+    f.m = h->model; f.gsum = h->d_gsum + (size_t)(h->step & 1) * 2 * h->E; f.m_out = m_out; f.ws_out = ws_out;
     f.tlen = h->tlen; f.ntiles = ntiles; f.e = e;
     const dim3 grid((unsigned)((h->p.L + TILE * WAVES - 1) / (TILE * WAVES))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
@@ -1097,24 +1383,113 @@ int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, i
     return APS_OK;
 }
 
-int do_propose(aps_handle *h, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+enum { KIND_PAIR = 0, KIND_PROPOSE, KIND_CLAIM, KIND_APPLY, KIND_PLAN, KIND_PROPOSE_LATTICE, KIND_FIELD_UPDATE, KIND_END, KIND_N = KIND_END };
+
+// profiling runs only: an event in front of the launch that follows (KIND_END closes the last one of a step)
+int prof_mark(aps_handle *h, int kind) {
+    if (!h->profiling) return APS_OK;
+    if (h->prof_n >= h->events.size()) {
+        hipEvent_t ev;
+        HIP_TRY(h, hipEventCreate(&ev));
+        h->events.push_back(ev);
+    }
+    HIP_TRY(h, hipEventRecord(h->events[h->prof_n++], h->stream));
+    h->prof_kind.push_back(kind);
+    return APS_OK;
+}
+
+LatticeArgs lattice_args(aps_handle *h, bool hook, bool write_prop) {
+    LatticeArgs a{};
+    a.m = h->model; a.src = h->d_src; a.orig = h->d_orig; a.ws = h->d_ws; a.occ_site = h->d_occ_site;
+    a.par = (int)(h->step & 1);
+    a.gsum = h->d_gsum + (size_t)a.par * 2 * h->E; a.gsum_next = h->d_gsum + (size_t)(a.par ^ 1) * 2 * h->E;
+    a.beta = h->d_beta; a.anchor = h->d_anchor; a.prop = h->d_prop; a.pcnt = h->d_pcnt; a.plist = h->d_plist;
+    a.dcnt = h->model.field_mode ? h->d_dcnt : nullptr; a.stepw = h->d_stepw;
+    a.S_out = hook ? h->d_S : nullptr; a.W_out = hook ? h->d_W : nullptr; a.occ4_out = hook ? h->d_occ4 : nullptr;
+    a.fuse_claim = (h->world == 1 && write_prop) ? 1 : 0; a.write_prop = write_prop ? 1 : 0;
+    a.Npad = (int)h->Npad; a.SH = (int)h->SH; a.E = h->E; a.nb = h->nb;
+    a.tile_lo = (int)(h->rank * h->SH / TILE); a.tile_cnt = (int)(h->SH / TILE);
+    return a;
+}
+
+int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, int ntiles, double *m_out, double2 *ws_out);
+
+// (re)build W, S on all sites from the particles (state upload; afterwards the field is kept incrementally)
+int ensure_lattice(aps_handle *h) {
+    if (h->method != APS_METHOD_LATTICE) return APS_OK;
+    if (h->field_dirty) {
+        if (h->model.field_mode)
+            for (int e = 0; e < h->E; ++e) {
+                int rc = launch_field(h, e, h->d_sp8 + (size_t)e * h->Npad, h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles,
+                                      nullptr, h->d_ws + (size_t)e * h->p.L);
+                if (rc) return rc;
+            }
+        h->field_dirty = false;
+    }
+    const unsigned long long s = (unsigned long long)h->step;
+    HIP_TRY(h, hipMemcpyAsync(h->d_stepw + (h->step & 1), &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+int launch_lattice_propose(aps_handle *h, const LatticeArgs &a, int first_tile, int tile_cnt) {
+    LatticeArgs b = a;
+    b.tile_lo = first_tile; b.tile_cnt = tile_cnt;
+    int rc = prof_mark(h, KIND_PROPOSE_LATTICE);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((tile_cnt * TILE + 255) / 256), (unsigned)h->E);
+    hipLaunchKernelGGL(propose_lattice, grid, dim3(256), 0, h->stream, b);
+    HIP_TRY(h, hipGetLastError());
+    return APS_OK;
+}
+
+int launch_field_update(aps_handle *h) {
+    if (!h->model.field_mode) return APS_OK;
+    int rc = prof_mark(h, KIND_FIELD_UPDATE);
+    if (rc) return rc;
+    FieldUpdArgs f{h->p.L, h->tlen, h->bshift, h->nb, h->dcap, h->d_ws, h->d_dcnt, h->d_dep};
+    const int R = h->fu_R;
+    const dim3 grid((unsigned)((h->p.L + FU_THREADS * R - 1) / (FU_THREADS * R)), (unsigned)h->E), block(FU_THREADS);
+    const size_t lds = fu_lds_bytes(h->tlen, h->table_in_lds);
+#define APS_FU(BC, TL, RR) hipLaunchKernelGGL((field_update<BC, TL, RR>), grid, block, lds, h->stream, f, h->d_table)
+#define APS_FU_R(BC, TL) do { if (R == 4) APS_FU(BC, TL, 4); else if (R == 2) APS_FU(BC, TL, 2); else APS_FU(BC, TL, 1); } while (0)
+    if (h->p.periodic) { if (h->table_in_lds) APS_FU_R(1, true); else APS_FU_R(1, false); }
+    else { if (h->table_in_lds) APS_FU_R(0, true); else APS_FU_R(0, false); }
+#undef APS_FU_R
+#undef APS_FU
+    HIP_TRY(h, hipGetLastError());
+    return APS_OK;
+}
+
+int do_propose(aps_handle *h) {
+    if (h->method == APS_METHOD_LATTICE) {
+        const LatticeArgs a = lattice_args(h, false, true);
+        return launch_lattice_propose(h, a, a.tile_lo, a.tile_cnt);
+    }
     const PairArgs a = pair_args(h, false, true);
-    return launch_pair(h, a, a.tile_lo, a.tile_cnt, ev0, ev1);
+    return launch_pair(h, a, a.tile_lo, a.tile_cnt);
 }
 
 int do_commit(aps_handle *h) {
     const CommitArgs c = commit_args(h);
     const dim3 grid((unsigned)(h->Npad / 256), (unsigned)h->E), block(256);
-    if (h->world != 1) hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);   // one GPU: propose() registered the hops
+    int rc;
+    if (h->world != 1) {                                     // one GPU: the propose kernel registered the hops
+        if ((rc = prof_mark(h, KIND_CLAIM))) return rc;
+        hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);
+    }
+    if ((rc = prof_mark(h, KIND_APPLY))) return rc;
     hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
     HIP_TRY(h, hipGetLastError());
     h->step += 1;
-    if (++h->plan_age >= h->plan_interval) {                 // source-tile lists for the following step(s)
-        int rc = launch_plan(h, (int)(h->rank * h->SH / TILE), (int)(h->SH / TILE));
-        if (rc) return rc;
+    if (h->method == APS_METHOD_LATTICE) {
+        h->plan_dirty = true;                                // the all-pairs hook replans when it is used
+        if ((rc = launch_field_update(h))) return rc;
+    } else if (++h->plan_age >= h->plan_interval) {          // source-tile lists for the following step(s)
+        if ((rc = launch_plan(h, (int)(h->rank * h->SH / TILE), (int)(h->SH / TILE)))) return rc;
         h->plan_dirty = false;
     }
-    return APS_OK;
+    return prof_mark(h, KIND_END);
 }
 
 bool all_set(const aps_handle *h) {
@@ -1125,6 +1500,8 @@ bool all_set(const aps_handle *h) {
 }  // namespace
 
 // ================================================================================== C ABI
+namespace { int download_hook(aps_handle *h, int e, double *S, double *W, int32_t *occ4); }
+
 extern "C" {
 
 int aps_device_count(void) {
@@ -1146,6 +1523,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
     if (!(p->dt > 0.0)) return bad("dt must be > 0");
     if (!p->beta) return bad("beta pointer is null");
     if (p->world < 1 || p->rank < 0 || p->rank >= p->world) return bad("bad rank/world");
+    if (p->method != APS_METHOD_AUTO && p->method != APS_METHOD_PAIRS && p->method != APS_METHOD_LATTICE) return bad("method must be APS_METHOD_AUTO, _PAIRS or _LATTICE");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "aps_create: no HIP device"; return APS_ERR_NODEVICE; }
     if (p->device < 0 || p->device >= ndev) return bad("device ordinal out of range");
@@ -1169,6 +1547,21 @@ int aps_create(const aps_params *p, aps_handle **out) {
     M.k_exit = p->k_exit; M.dt = p->dt; M.seed_lo = (uint32_t)p->seed; M.seed_hi = (uint32_t)(p->seed >> 32);
     M.ens_base = p->ensemble_base;
     build_table(h);
+    // formulation: lattice (incremental field on the L sites) unless asked otherwise or its deposit lists would be huge
+    {
+        const int B = 1 << h->bshift;
+        h->nb = (p->L + B - 1) / B;
+        h->dcap = (int)std::min<int64_t>(2LL * p->K * B, std::max<int64_t>(2 * p->n_particles, 2));
+        const double dep_bytes = (double)h->E * h->nb * h->dcap * 4.0;
+        h->method = p->method == APS_METHOD_AUTO ? (dep_bytes <= 16e9 ? APS_METHOD_LATTICE : APS_METHOD_PAIRS) : p->method;
+        if (const char *env = std::getenv("APS_METHOD")) {    // test / tuning knob for method = auto
+            if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "pairs")) h->method = APS_METHOD_PAIRS;
+            if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "lattice")) h->method = APS_METHOD_LATTICE;
+        }
+        const int64_t blocks1 = ((int64_t)p->L + FU_THREADS - 1) / FU_THREADS * h->E;   // sites per lane so that the grid still fills the chip
+        h->fu_R = blocks1 >= 4 * 1024 ? 4 : (blocks1 >= 2 * 384 ? 2 : 1);
+        if (const char *env = std::getenv("APS_FU_R")) { const int r = std::atoi(env); if (r == 1 || r == 2 || r == 4) h->fu_R = r; }
+    }
     // A particle moves at most one site per step, so tile bounds drift by <= 1 per step: when nobody can die
     // (has-dead flags are then static) or wrap around, a plan with a 16-site margin serves 8 steps.
     h->plan_interval = (!p->periodic && !(p->k_exit > 0.0)) ? 8 : 1;
@@ -1195,6 +1588,12 @@ int aps_create(const aps_params *p, aps_handle **out) {
         (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))
         return die(rc);
     h->d_prop = h->d_prop_own;
+    if (h->method == APS_METHOD_LATTICE) {
+        if ((rc = dev_alloc(h, &h->d_ws, EL)) || (rc = dev_alloc(h, &h->d_occ_site, EL)) ||
+            (rc = dev_alloc(h, &h->d_dcnt, (size_t)h->E * h->nb)) || (rc = dev_alloc(h, &h->d_dep, (size_t)h->E * h->nb * h->dcap)) ||
+            (rc = dev_alloc(h, &h->d_stepw, 2)))
+            return die(rc);
+    }
     if (p->anchor_mask) {
         if ((rc = dev_alloc(h, &h->d_anchor, (size_t)p->L))) return die(rc);
         if (hipMemcpyAsync(h->d_anchor, p->anchor_mask, (size_t)p->L, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "anchor upload failed"; return die(APS_ERR_HIP); }
@@ -1212,6 +1611,9 @@ void aps_destroy(aps_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (void *q : {(void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
                     h->d_nexit, h->d_tmp_sp8, h->d_tmp_tinfo};
@@ -1244,6 +1646,11 @@ int aps_set_state(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *si
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + (size_t)(h->step & 1) * 2 * h->E + 2 * e, gsum, sizeof(gsum), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_nexit + e, 0, sizeof(unsigned), h->stream));
+    if (h->d_occ_site) {
+        static_assert(sizeof(int) == sizeof(uint32_t), "occupancy upload");
+        HIP_TRY(h, hipMemcpyAsync(h->d_occ_site + (size_t)e * h->p.L, occ.data(), (size_t)h->p.L * 4, hipMemcpyHostToDevice, h->stream));
+        h->field_dirty = true;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_set[(size_t)e] = n;
     return APS_OK;
@@ -1281,6 +1688,14 @@ int aps_pair_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t 
     if (!h->d_S && ((rc = dev_alloc(h, &h->d_S, EN)) || (rc = dev_alloc(h, &h->d_W, EN)) || (rc = dev_alloc(h, &h->d_occ4, EN * 4)))) return rc;
     const PairArgs a = pair_args(h, true, false);
     if ((rc = launch_pair(h, a, 0, (int)h->ntiles))) return rc;            // the hook covers every tile, not only this rank's
+    return download_hook(h, e, S, W, occ4);
+}
+
+}  // extern "C"
+
+namespace {
+// per-slot hook outputs of ensemble e -> caller's arrays in original particle order
+int download_hook(aps_handle *h, int e, double *S, double *W, int32_t *occ4) {
     std::vector<double> s((size_t)h->Npad), w((size_t)h->Npad); std::vector<int> o((size_t)h->Npad * 4); std::vector<uint32_t> orig((size_t)h->Npad);
     HIP_TRY(h, hipMemcpyAsync(s.data(), h->d_S + (size_t)e * h->Npad, s.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(w.data(), h->d_W + (size_t)e * h->Npad, w.size() * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1295,10 +1710,15 @@ int aps_pair_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t 
     }
     return APS_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int aps_propose(aps_handle *h) {
     if (!h) return APS_ERR_ARG;
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_propose: upload a state for every ensemble first");
+    int rc = ensure_lattice(h);
+    if (rc) return rc;
     return do_propose(h);
 }
 
@@ -1308,60 +1728,169 @@ int aps_commit(aps_handle *h) {
     return do_commit(h);
 }
 
+}  // extern "C"
+
+namespace {
+
+constexpr int GRAPH_STEPS = 32;       // steps per captured graph (even: the kernels' parity arguments are baked in)
+
+// Lattice steps are a few microseconds of GPU time each, less than the host needs to launch their kernels
+// one by one: GRAPH_STEPS steps are captured once (the step index lives in device memory, see stepw) and replayed.
+int build_graph(aps_handle *h) {
+    if (h->gexec) return APS_OK;
+    if (!h->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    const hipStream_t user_stream = h->stream;
+    const int64_t step0 = h->step;
+    HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    h->stream = h->cap_stream;
+    int rc = APS_OK;
+    for (int k = 0; k < GRAPH_STEPS && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
+    h->stream = user_stream;
+    h->step = step0;
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { h->gexec = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    h->graph_steps = GRAPH_STEPS;
+    return APS_OK;
+}
+
+int one_step(aps_handle *h) {
+    int rc;
+    if ((rc = do_propose(h))) return rc;
+    if (h->comm) {                                           // one in-place all-gather of 1 byte per particle
+        const size_t block = (size_t)h->E * (size_t)h->SH;
+        const ncclResult_t nr = g_rccl.AllGather(h->d_prop + block * (size_t)h->rank, h->d_prop, block, ncclUint8, h->comm, h->stream);
+        if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
+    }
+    return do_commit(h);
+}
+
+int run_profiled(aps_handle *h, int64_t nsteps, double ms[KIND_N], int64_t counts[KIND_N], double *work) {
+    for (int k = 0; k < KIND_N; ++k) { ms[k] = 0.0; counts[k] = 0; }
+    if (work) *work = 0.0;
+    int rc = ensure_lattice(h);
+    if (rc) return rc;
+    std::vector<uint32_t> pn((size_t)h->E * std::max<int64_t>(h->ntiles / RT, h->nb));
+    for (int64_t s = 0; s < nsteps; ++s) {
+        h->profiling = true; h->prof_n = 0; h->prof_kind.clear();
+        rc = one_step(h);
+        h->profiling = false;
+        if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i + 1 < h->prof_n; ++i) {
+            const int kind = h->prof_kind[i];
+            if (kind == KIND_END) continue;
+            float t = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&t, h->events[i], h->events[i + 1]));
+            ms[kind] += t; counts[kind] += 1;
+        }
+        if (work && (s == 0 || s == nsteps - 1)) {           // the work per step changes slowly: sample first and last step
+            const double wgt = nsteps == 1 ? 1.0 : 0.5 * (double)nsteps;
+            double t = 0.0;
+            if (h->method == APS_METHOD_LATTICE) {           // deposits of the step just taken
+                if (h->model.field_mode) {
+                    HIP_TRY(h, hipMemcpy(pn.data(), h->d_dcnt, (size_t)h->E * h->nb * 4, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < (size_t)h->E * h->nb; ++i) t += (double)pn[i];
+                }
+            } else {                                         // (target tile, source tile) blocks = RT x sum of the list lengths
+                HIP_TRY(h, hipMemcpy(pn.data(), h->d_plan_n, (size_t)h->E * (h->ntiles / RT) * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < (size_t)h->E * (h->ntiles / RT); ++i) t += (double)pn[i] * RT * TILE * TILE;
+            }
+            *work += t * wgt;
+        }
+    }
+    return APS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int aps_step(aps_handle *h, int64_t nsteps) {
     if (!h) return APS_ERR_ARG;
     if (nsteps < 0) return fail(h, APS_ERR_ARG, "aps_step: nsteps < 0");
     if (h->world != 1 && !h->comm)
         return fail(h, APS_ERR_STATE, "aps_step: sharded handle without communicator; call aps_comm_init, or use aps_propose / exchange / aps_commit");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step: upload a state for every ensemble first");
-    const size_t block = (size_t)h->E * (size_t)h->SH;
-    for (int64_t s = 0; s < nsteps; ++s) {
-        int rc;
-        if ((rc = do_propose(h))) return rc;
-        if (h->comm) {                                       // one in-place all-gather of 1 byte per particle
-            const ncclResult_t nr = g_rccl.AllGather(h->d_prop + block * (size_t)h->rank, h->d_prop, block, ncclUint8, h->comm, h->stream);
-            if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
+    int rc = ensure_lattice(h);
+    if (rc) return rc;
+    int64_t s = 0;
+    static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
+    if (h->method == APS_METHOD_LATTICE && h->world == 1 && !no_graph && nsteps >= GRAPH_STEPS + 1) {
+        if (h->step & 1) { if ((rc = one_step(h))) return rc; ++s; }       // the graph starts on an even step
+        if ((rc = build_graph(h))) return rc;
+        for (; nsteps - s >= h->graph_steps; s += h->graph_steps) {
+            HIP_TRY(h, hipGraphLaunch(h->gexec, h->stream));
+            h->step += h->graph_steps;
         }
-        if ((rc = do_commit(h))) return rc;
     }
+    for (; s < nsteps; ++s)
+        if ((rc = one_step(h))) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
 }
 
-int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_t *launches, double *pairs) {
+int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *launches, double *work) {
     if (!h) return APS_ERR_ARG;
-    if (nsteps < 0 || !pair_kernel_ms) return fail(h, APS_ERR_ARG, "aps_step_timed: bad argument");
+    if (nsteps < 0 || !kernel_ms) return fail(h, APS_ERR_ARG, "aps_step_timed: bad argument");
     if (h->world != 1) return fail(h, APS_ERR_STATE, "aps_step_timed: sharded handle");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step_timed: upload a state for every ensemble first");
-    while ((int64_t)h->events.size() < 2 * nsteps) {
-        hipEvent_t ev;
-        HIP_TRY(h, hipEventCreate(&ev));
-        h->events.push_back(ev);
+    double ms[KIND_N]; int64_t cnt[KIND_N];
+    int rc = run_profiled(h, nsteps, ms, cnt, work);
+    if (rc) return rc;
+    const int kind = h->method == APS_METHOD_LATTICE ? KIND_FIELD_UPDATE : KIND_PAIR;
+    *kernel_ms = ms[kind];
+    if (launches) *launches = cnt[kind];
+    return APS_OK;
+}
+
+int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launches7) {
+    if (!h) return APS_ERR_ARG;
+    if (nsteps < 0 || !ms7) return fail(h, APS_ERR_ARG, "aps_step_profile: bad argument");
+    if (h->world != 1) return fail(h, APS_ERR_STATE, "aps_step_profile: sharded handle");
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step_profile: upload a state for every ensemble first");
+    double ms[KIND_N]; int64_t cnt[KIND_N];
+    int rc = run_profiled(h, nsteps, ms, cnt, nullptr);
+    if (rc) return rc;
+    for (int k = 0; k < KIND_N; ++k) { ms7[k] = ms[k]; if (launches7) launches7[k] = cnt[k]; }
+    return APS_OK;
+}
+
+int aps_method(aps_handle *h) { return h ? h->method : APS_ERR_ARG; }
+
+int aps_lattice_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t *occ4, int64_t n) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !S || !W || !occ4) return fail(h, APS_ERR_ARG, "aps_lattice_accumulate: bad argument");
+    if (h->method != APS_METHOD_LATTICE) return fail(h, APS_ERR_STATE, "aps_lattice_accumulate: handle uses the all-pairs formulation");
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_lattice_accumulate: upload a state for every ensemble first");
+    if (n != h->n_set[(size_t)e]) return fail(h, APS_ERR_ARG, "aps_lattice_accumulate: n differs from the uploaded particle count");
+    const size_t EN = (size_t)h->E * (size_t)h->Npad;
+    int rc;
+    if (!h->d_S && ((rc = dev_alloc(h, &h->d_S, EN)) || (rc = dev_alloc(h, &h->d_W, EN)) || (rc = dev_alloc(h, &h->d_occ4, EN * 4)))) return rc;
+    if ((rc = ensure_lattice(h))) return rc;
+    const LatticeArgs a = lattice_args(h, true, false);
+    if ((rc = launch_lattice_propose(h, a, 0, (int)h->ntiles))) return rc;
+    return download_hook(h, e, S, W, occ4);
+}
+
+int aps_get_lattice(aps_handle *h, int32_t e, double *W, double *S, int32_t *occ) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_get_lattice: bad ensemble");
+    if (h->method != APS_METHOD_LATTICE) return fail(h, APS_ERR_STATE, "aps_get_lattice: handle uses the all-pairs formulation");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_get_lattice: no state uploaded for this ensemble");
+    int rc = ensure_lattice(h);
+    if (rc) return rc;
+    const size_t L = (size_t)h->p.L;
+    if (W || S) {
+        std::vector<double2> ws(L, make_double2(0.0, 0.0));
+        if (h->model.field_mode) HIP_TRY(h, hipMemcpy(ws.data(), h->d_ws + (size_t)e * L, L * sizeof(double2), hipMemcpyDeviceToHost));
+        for (size_t x = 0; x < L; ++x) { if (W) W[x] = ws[x].x; if (S) S[x] = ws[x].y; }
     }
-    double tiles = 0.0;                                     // (target tile, source tile) blocks = RT x sum of the list lengths
-    std::vector<uint32_t> pn((size_t)h->E * (h->ntiles / RT));
-    for (int64_t s = 0; s < nsteps; ++s) {
-        int rc;
-        if ((rc = do_propose(h, h->events[(size_t)(2 * s)], h->events[(size_t)(2 * s + 1)]))) return rc;
-        if (pairs && (s == 0 || s == nsteps - 1)) {         // the lists change slowly: sample first and last step
-            HIP_TRY(h, hipMemcpyAsync(pn.data(), h->d_plan_n, pn.size() * 4, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            double t = 0.0;
-            for (uint32_t v : pn) t += (double)v * RT;
-            tiles += t * (nsteps == 1 ? 1.0 : 0.5 * (double)nsteps);
-        }
-        if ((rc = do_commit(h))) return rc;
-    }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    double total = 0.0;
-    for (int64_t s = 0; s < nsteps; ++s) {
-        float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->events[(size_t)(2 * s)], h->events[(size_t)(2 * s + 1)]));
-        total += ms;
-    }
-    *pair_kernel_ms = total;
-    if (launches) *launches = nsteps;
-    if (pairs) *pairs = tiles * TILE * TILE;
+    if (occ) HIP_TRY(h, hipMemcpy(occ, h->d_occ_site + (size_t)e * L, L * 4, hipMemcpyDeviceToHost));
     return APS_OK;
 }
 
@@ -1434,6 +1963,7 @@ int aps_exchange_buffer(aps_handle *h, void **dev_ptr, int64_t *total_bytes, int
 
 int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes) {
     if (!h) return APS_ERR_ARG;
+    if (h->gexec) { (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // captured kernels hold the old pointer
     if (!dev_ptr) { h->d_prop = h->d_prop_own; return APS_OK; }
     if (nbytes < (int64_t)h->E * h->SH * h->world) return fail(h, APS_ERR_ARG, "aps_bind_exchange_buffer: buffer too small");
     HIP_TRY(h, hipStreamSynchronize(h->stream));

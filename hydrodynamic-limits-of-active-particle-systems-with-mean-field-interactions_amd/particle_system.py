@@ -30,7 +30,7 @@ class ParticleSystem:
                  site_capacity=1, crowding_suppresses_rates=False, k_on=0.1, k_off=0.01,
                  suppress_flip_when_bound=True, k_exit=0,
                  # extensions (all optional, after the reference's keywords)
-                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode="sync"):
+                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode="sync", method="auto"):
         self.L = int(L)
         self.xlim = xlim
         self.K = int(site_capacity)
@@ -87,6 +87,9 @@ class ParticleSystem:
         if mode not in ("sync", "gillespie"):
             raise ValueError("mode must be 'sync' (fixed-dt stepper) or 'gillespie' (one exact event per iteration)")
         self.mode = mode
+        if method not in capi.METHODS:
+            raise ValueError("method must be 'auto', 'pairs' (all-pairs kernel) or 'lattice' (incremental lattice field)")
+        self.method = method
         self._handle = None
         self._util = None                      # lazily created handle for compute_local_m_field / step_gillespie
 
@@ -144,7 +147,7 @@ class ParticleSystem:
             dt=self.dt, seed=seed, n_particles=n_particles, minus_anchor=self.minus_anchor,
             immobilize=self.immobilize_when_anchored, suppress_flip=self.suppress_flip_when_bound,
             crowding=self.crowding_suppresses_rates, k_on=self.k_on, k_off=self.k_off, k_exit=self.k_exit,
-            anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site)
+            anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site, method=self.method)
 
     def _utility_handle(self):
         if self._util is None:

@@ -50,8 +50,19 @@ typedef struct aps_params {
     int32_t rank, world;        /* particle-index shard of this handle (world = 1: everything) */
     int32_t sort_by_site;       /* 1: keep particles ordered by site internally (tile culling) */
     int32_t ensemble_base;      /* Philox counter word 3 of local ensemble e is ensemble_base + e */
-    int32_t reserved[3];
+    int32_t method;             /* APS_METHOD_*: which formulation of the mean field the stepper uses */
+    int32_t reserved[2];
 } aps_params;
+
+/* Two formulations of compute_local_m_field (ref :216-246); both give the same bits (exact weight grid):
+ *   PAIRS    all-pairs tile kernel: every step each particle sums w(d_ij) over all particles in reach
+ *   LATTICE  the reference's own histogram -> smoothing -> gather, with the smoothed histograms
+ *            tot_conv = W(x), s_conv = S(x) (ref :224-238) kept on the L sites and updated incrementally by the
+ *            accepted events of each step; site occupancy (ref :248-252) likewise
+ *   AUTO     LATTICE unless its per-bucket deposit lists would not fit (E*L*K*8 bytes > 16 GB) */
+#define APS_METHOD_AUTO 0
+#define APS_METHOD_PAIRS 1
+#define APS_METHOD_LATTICE 2
 
 int aps_device_count(void);
 const char *aps_last_error(const aps_handle *h);   /* h may be NULL: error of the last failed aps_create */
@@ -76,6 +87,17 @@ int aps_get_state(aps_handle *h, int32_t ensemble, int32_t *pos, int8_t *sigma, 
  * (ref :216-246 in all-pairs form) and occ4 = occupancy of {own, forward, left, right} target site
  * (ref :294-301).  Arrays are [n] / [n] / [4n] in original order. */
 int aps_pair_accumulate(aps_handle *h, int32_t ensemble, double *S, double *W, int32_t *occ4, int64_t n);
+
+/* Parity hook for the lattice formulation: the same quantities as aps_pair_accumulate, read from the
+ * incrementally maintained lattice arrays at the particles' sites (m_field[pos], occ_total[target], ref :261, :294-301). */
+int aps_lattice_accumulate(aps_handle *h, int32_t ensemble, double *S, double *W, int32_t *occ4, int64_t n);
+
+/* The maintained lattice arrays themselves: W = tot_conv, S = s_conv (ref :224-238, unnormalised taps on the weight
+ * grid) and occ = occ_total (ref :248-252), each [L]; any pointer may be NULL.  LATTICE handles only. */
+int aps_get_lattice(aps_handle *h, int32_t ensemble, double *W, double *S, int32_t *occ);
+
+/* APS_METHOD_PAIRS or APS_METHOD_LATTICE: what AUTO resolved to. */
+int aps_method(aps_handle *h);
 
 /* replaces the body of the `while t < T` loop (ref :511-516): nsteps synchronous steps of dt.
  * Sharded handles (world > 1) need aps_comm_init first (or the caller drives propose/exchange/commit). */
@@ -124,10 +146,14 @@ int aps_get_table(aps_handle *h, double *out, int32_t cap, int32_t *tlen, int32_
 /* Re-establish the site-sorted internal order (no effect on results; speeds up tile culling). */
 int aps_resort(aps_handle *h);
 
-/* Measurement: run nsteps steps with HIP events around every launch of the all-pairs kernel (pair_accumulate
- * alone) on the handle's stream; returns their summed duration, the number of launches and pair evaluations. */
-int aps_step_timed(aps_handle *h, int64_t nsteps, double *pair_kernel_ms, int64_t *launches,
-                   double *pairs_evaluated);
+/* Measurement: run nsteps steps (launched one by one, no graph replay) with HIP events around every launch of the
+ * field kernel alone -- pair_accumulate (PAIRS) or field_update (LATTICE) -- on the handle's stream; returns
+ * their summed duration, the number of launches and the work done: pair evaluations (PAIRS) or deposits (LATTICE). */
+int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *launches, double *work);
+
+/* The same for every kernel of the step: ms7[k] / launches7[k] summed over nsteps, k = pair_accumulate, propose,
+ * claim, apply, plan_tiles, propose_lattice, field_update. */
+int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launches7);
 
 #ifdef __cplusplus
 }

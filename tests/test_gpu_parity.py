@@ -4,7 +4,9 @@ Bars (DESIGN.md "Parity"):
   weight table, S, W, occ4, m-field .... bit-exact vs oracle/sync_oracle.c (sums are exact on the 2^-q grid)
   integer state (pos, sigma, bound, alive) after every step .... bit-exact vs the oracle
   m-field vs the REFERENCE fixture G1 .... <= 2e-11 (weight-grid rounding, same bound as the oracle's)
-The oracle uses the lattice formulation (histogram + windowed stencil), the GPU the all-pairs one."""
+The oracle uses the lattice formulation recomputed from scratch every step (histogram + windowed stencil); the GPU
+is run in BOTH of its formulations (`method`): the all-pairs kernel, and the lattice field maintained incrementally
+(whose W, S and occupancy arrays are additionally compared with the oracle's recomputation after the runs)."""
 import importlib
 
 import numpy as np
@@ -22,6 +24,29 @@ def capi():
     mod = importlib.import_module(PKG + ".capi")
     assert mod.device_count() >= 1, "no GPU visible"
     return mod
+
+
+@pytest.fixture(params=["pairs", "lattice"])
+def method(request):
+    return request.param
+
+
+def check_lattice(h, orc, ensemble=0):
+    """The incrementally maintained lattice arrays equal the oracle's from-scratch recomputation, bit for bit."""
+    if h.method != "lattice":
+        return
+    W, S, occ = h.get_lattice(ensemble)
+    cp0, cm0, _ = orc.field_sites()
+    assert np.array_equal(occ, cp0 + cm0)
+    if orc.par.sigma_kernel > 0:
+        S0, W0 = orc.last_site_sums
+        assert np.array_equal(W, W0)
+        assert np.array_equal(S, S0)
+    Sp, Wp, occ4 = h.lattice_accumulate(ensemble)
+    S1, W1, occ1 = orc.pair_sums()
+    assert np.array_equal(occ4, occ1)
+    if orc.par.sigma_kernel > 0:
+        assert np.array_equal(Sp, S1) and np.array_equal(Wp, W1)
 
 
 def make_handle(capi, par, n, dt=0.05, seed=1, beta=None, **kw):
@@ -56,7 +81,7 @@ FIELD_CASES = [
 
 @pytest.mark.parametrize("case", FIELD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 @pytest.mark.parametrize("sort", [True, False], ids=["sorted", "unsorted"])
-def test_table_and_pair_sums_bit_exact(capi, case, sort):
+def test_table_and_pair_sums_bit_exact(capi, case, sort, method):
     par = params(**case)
     rng = np.random.default_rng(42)
     N = int(0.55 * par.L * par.K)
@@ -64,12 +89,14 @@ def test_table_and_pair_sums_bit_exact(capi, case, sort):
     alive = (rng.random(N) > 0.1).astype(np.uint8)            # some dead particles must be inert
     orc = so.SyncOracle(par, dt=0.05, seed=1)
     orc.set_state(pos, spin, alive=alive)
-    h = make_handle(capi, par, N, sort_by_site=sort)
+    h = make_handle(capi, par, N, sort_by_site=sort, method=method)
     try:
+        assert h.method == method
         tab, q = h.table()
         if par.sigma_kernel > 0:
             assert q == orc.q and np.array_equal(tab, orc.table)
         h.set_state(pos, spin, alive=alive)
+        check_lattice(h, orc)
         S, W, occ4 = h.pair_accumulate()
         S0, W0, occ0 = orc.pair_sums()
         assert np.array_equal(W, W0)
@@ -132,7 +159,7 @@ STEP_CASES = [
 
 @pytest.mark.parametrize("case", STEP_CASES, ids=lambda c: c["tag"])
 @pytest.mark.parametrize("sort", [True, False], ids=["sorted", "unsorted"])
-def test_trajectory_bit_exact_every_step(capi, case, sort):
+def test_trajectory_bit_exact_every_step(capi, case, sort, method):
     case = dict(case)
     tag, frac = case.pop("tag"), case.pop("frac")
     par = params(**case)
@@ -142,7 +169,7 @@ def test_trajectory_bit_exact_every_step(capi, case, sort):
     dt, seed = 0.04, 20260101
     orc = so.SyncOracle(par, dt=dt, seed=seed)
     orc.set_state(pos, spin)
-    h = make_handle(capi, par, N, dt=dt, seed=seed, sort_by_site=sort)
+    h = make_handle(capi, par, N, dt=dt, seed=seed, sort_by_site=sort, method=method)
     try:
         h.set_state(pos, spin)
         nsteps = 120
@@ -156,6 +183,8 @@ def test_trajectory_bit_exact_every_step(capi, case, sort):
             assert np.array_equal(bd, orc.bound), (tag, s)
             if s == 60:
                 h.resort()                      # re-sorting must not change anything observable
+            if s % 40 == 39:
+                check_lattice(h, orc)
         t, k = h.time()
         assert k == nsteps and t == nsteps * dt
         ex, ex0 = h.exits(), orc.exits()
@@ -169,12 +198,12 @@ def test_trajectory_bit_exact_every_step(capi, case, sort):
         h.close()
 
 
-def test_propose_commit_halves_equal_step(capi):
+def test_propose_commit_halves_equal_step(capi, method):
     par = params(L=500, K=2, sigma=0.02)
     rng = np.random.default_rng(3)
     pos, spin = random_state(rng, 500, 600, 2)
-    a = make_handle(capi, par, 600, seed=5)
-    b = make_handle(capi, par, 600, seed=5)
+    a = make_handle(capi, par, 600, seed=5, method=method)
+    b = make_handle(capi, par, 600, seed=5, method=method)
     try:
         a.set_state(pos, spin)
         b.set_state(pos, spin)
@@ -191,19 +220,19 @@ def test_propose_commit_halves_equal_step(capi):
         b.close()
 
 
-def test_ensembles_are_independent_and_match_single_runs(capi):
+def test_ensembles_are_independent_and_match_single_runs(capi, method):
     """BASELINE config 4 shape: E ensembles with their own beta in one handle == E separate handles."""
     par = params(L=400, K=1, sigma=0.02)
     rng = np.random.default_rng(9)
     betas = [0.0, 0.7, 1.5, 3.0]
     states = [random_state(rng, 400, 180, 1) for _ in betas]
-    big = make_handle(capi, par, 180, seed=11, beta=betas)
+    big = make_handle(capi, par, 180, seed=11, beta=betas, method=method)
     try:
         for e, (p, s) in enumerate(states):
             big.set_state(p, s, ensemble=e)
         big.step(60)
         for e, (p, s) in enumerate(states):
-            one = make_handle(capi, par, 180, seed=11, beta=[betas[e]], ensemble_base=e)
+            one = make_handle(capi, par, 180, seed=11, beta=[betas[e]], ensemble_base=e, method=method)
             orc_par = params(L=400, K=1, sigma=0.02, beta=betas[e])
             orc = so.SyncOracle(orc_par, dt=0.05, seed=11, ensemble=e)
             try:
@@ -215,6 +244,7 @@ def test_ensembles_are_independent_and_match_single_runs(capi):
                 for x, y in zip(got, one.get_state()):
                     assert np.array_equal(x, y)
                 assert np.array_equal(got[0], orc.pos) and np.array_equal(got[1], orc.spin)
+                check_lattice(big, orc, ensemble=e)
             finally:
                 one.close()
     finally:
@@ -239,7 +269,7 @@ def test_error_paths(capi):
         h.close()
 
 
-def test_full_size_properties(capi):
+def test_full_size_properties(capi, method):
     """BASELINE config 2 shape (N=1e5, L=2e5, K=1, sigma_g=1000): properties that need no oracle run:
     exclusion, conservation, |dx| <= 1 per step, sorted == unsorted bit for bit, a spot check of
     S/W against the oracle on a subset of targets via a small window state is covered elsewhere."""
@@ -249,8 +279,8 @@ def test_full_size_properties(capi):
     rng = np.random.default_rng(0)
     pos = rng.choice(L, size=N, replace=False).astype(np.int32)
     spin = rng.choice(np.array([1, -1], np.int8), size=N)
-    a = make_handle(capi, par, N, dt=0.0125, seed=0, sort_by_site=True)
-    b = make_handle(capi, par, N, dt=0.0125, seed=0, sort_by_site=False)
+    a = make_handle(capi, par, N, dt=0.0125, seed=0, sort_by_site=True, method=method)
+    b = make_handle(capi, par, N, dt=0.0125, seed=0, sort_by_site=False, method=method)
     try:
         a.set_state(pos, spin)
         b.set_state(pos, spin)
@@ -272,12 +302,22 @@ def test_full_size_properties(capi):
             prev = pa.astype(int)
         orc.run(15)
         assert np.array_equal(pa, orc.pos) and np.array_equal(sa, orc.spin)
+        check_lattice(a, orc)
+        if method == "lattice":                 # through the graph-replay path (>= 33 steps per call), field still exact
+            a.step(34)                          # (the oracle needs ~2 s per step at this size)
+            b.step(34)
+            orc.run(34)
+            pa, sa, _, _ = a.get_state()
+            assert np.array_equal(pa, orc.pos) and np.array_equal(sa, orc.spin)
+            assert np.array_equal(pa, b.get_state()[0])
+            check_lattice(a, orc)
+            check_lattice(b, orc)
     finally:
         a.close()
         b.close()
 
 
-def test_two_rank_shards_emulated_on_one_gpu(capi):
+def test_two_rank_shards_emulated_on_one_gpu(capi, method):
     """world=2 on ONE device: each handle evaluates its own particle shard, the proposal blocks are swapped
     by hand (what the all-gather does), both commit everything -> identical states, equal to world=1."""
     torch = pytest.importorskip("torch")
@@ -289,14 +329,14 @@ def test_two_rank_shards_emulated_on_one_gpu(capi):
     stream = torch.cuda.current_stream(dev).cuda_stream
     ranks = []
     for r in range(2):
-        h = make_handle(capi, par, N, dt=0.04, seed=8, rank=r, world=2)
+        h = make_handle(capi, par, N, dt=0.04, seed=8, rank=r, world=2, method=method)
         h.set_state(pos, spin)
         _, total, off, mine = h.exchange_buffer()
         buf = torch.zeros(total, dtype=torch.uint8, device=dev)
         h.set_stream(stream)
         h.bind_exchange_buffer(buf.data_ptr(), total)
         ranks.append((h, buf, off, mine))
-    single = make_handle(capi, par, N, dt=0.04, seed=8)
+    single = make_handle(capi, par, N, dt=0.04, seed=8, method=method)
     try:
         single.set_state(pos, spin)
         assert ranks[0][2] == 0 and ranks[1][2] == ranks[0][3]
@@ -317,6 +357,10 @@ def test_two_rank_shards_emulated_on_one_gpu(capi):
             for x, y in zip(h.get_state(), want):
                 assert np.array_equal(x, y)
         assert np.array_equal(ranks[0][0].exits(), single.exits())
+        if method == "lattice":
+            for h, _, _, _ in ranks:
+                for x, y in zip(h.get_lattice(), single.get_lattice()):
+                    assert np.array_equal(x, y)
     finally:
         for h, _, _, _ in ranks:
             h.close()
@@ -353,15 +397,15 @@ def test_hip_engine_over_nccl_world1(capi):
         dist.destroy_process_group()
 
 
-def test_inlibrary_rccl_allgather_world1(capi):
+def test_inlibrary_rccl_allgather_world1(capi, method):
     """aps_comm_init + aps_step with the library's own ncclAllGather (world size 1: the collective runs in place
     on one rank) must equal the plain single-GPU stepping."""
     pytest.importorskip("torch")                          # as in production: torch's librccl is the process's RCCL
     par = params(L=1500, K=2, sigma=0.02)
     rng = np.random.default_rng(6)
     pos, spin = random_state(rng, 1500, 900, 2)
-    a = make_handle(capi, par, 900, seed=3)
-    b = make_handle(capi, par, 900, seed=3)
+    a = make_handle(capi, par, 900, seed=3, method=method)
+    b = make_handle(capi, par, 900, seed=3, method=method)
     try:
         a.set_state(pos, spin)
         b.set_state(pos, spin)
@@ -379,7 +423,7 @@ def test_inlibrary_rccl_allgather_world1(capi):
         b.close()
 
 
-def test_table_too_large_for_lds_uses_global_table(capi):
+def test_table_too_large_for_lds_uses_global_table(capi, method):
     """sigma_g = 6000 -> 24001-entry table (188 KB) does not fit LDS: the kernels gather from the table in
     global memory instead.  Same bit-exact bars."""
     par = params(L=60000, K=1, sigma=0.1)
@@ -388,7 +432,7 @@ def test_table_too_large_for_lds_uses_global_table(capi):
     pos, spin = random_state(rng, par.L, N, par.K)
     orc = so.SyncOracle(par, dt=0.05, seed=9)
     orc.set_state(pos, spin)
-    h = make_handle(capi, par, N, seed=9)
+    h = make_handle(capi, par, N, seed=9, method=method)
     try:
         tab, q = h.table()
         assert len(tab) == 24001 and q == orc.q and np.array_equal(tab, orc.table)
@@ -402,6 +446,7 @@ def test_table_too_large_for_lds_uses_global_table(capi):
         assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin)
         m = h.observe()[2]
         assert np.array_equal(m, orc.field_sites()[2])
+        check_lattice(h, orc)
     finally:
         h.close()
 
@@ -424,7 +469,7 @@ def _random_case(rng):
     return kw
 
 
-def test_randomised_parameter_sweep_bit_exact(capi):
+def test_randomised_parameter_sweep_bit_exact(capi, method):
     """32 random parameter sets (tiny to medium lattices, K up to 5, every field mode, anchors, crowding, zero
     rates, wrap-around, particles dead from the start) -- integer state bit-exact against the oracle along 60 steps,
     S/W/occupancy and the m-field bit-exact at the start."""
@@ -440,7 +485,7 @@ def test_randomised_parameter_sweep_bit_exact(capi):
         dt, seed = float(rng.choice([0.002, 0.03, 0.2])), int(rng.integers(2 ** 62))
         orc = so.SyncOracle(par, dt=dt, seed=seed)
         orc.set_state(pos, spin, bound=bound, alive=alive)
-        h = make_handle(capi, par, N, dt=dt, seed=seed, sort_by_site=bool(case_no % 2))
+        h = make_handle(capi, par, N, dt=dt, seed=seed, sort_by_site=bool(case_no % 2), method=method)
         try:
             h.set_state(pos, spin, bound=bound, alive=alive)
             S, W, occ4 = h.pair_accumulate()
@@ -455,9 +500,43 @@ def test_randomised_parameter_sweep_bit_exact(capi):
                 assert np.array_equal(sg, orc.spin) and np.array_equal(bd, orc.bound), (case_no, chunk, kw)
                 if chunk == 2:
                     h.resort()
+                if chunk in (0, 5):
+                    check_lattice(h, orc)
             ex, ex0 = h.exits(), orc.exits()
             assert len(ex) == len(ex0)
             if len(ex0):
                 assert np.array_equal(ex, ex0[np.lexsort((ex0[:, 2], ex0[:, 0]))]), (case_no, kw)
         finally:
             h.close()
+
+
+@pytest.mark.parametrize("case", [dict(L=3000, K=1, sigma=0.01), dict(L=1200, K=2, sigma=0.02, periodic=True, k_exit=0.3, k_on=1.0, k_off=0.5,
+                                                                     anchor_positions=[0.4], anchor_radius=0.1),
+                                  dict(L=900, K=1, sigma=0.0)], ids=["reflect", "periodic_exits", "global_field"])
+def test_lattice_graph_replay_long_run(capi, case):
+    """Hundreds of steps in one aps_step call go through the captured-graph path (step index in device memory);
+    state, exit log and the maintained field must still equal the oracle's step-by-step recomputation."""
+    par = params(**case)
+    rng = np.random.default_rng(77)
+    N = int(0.5 * par.L * par.K)
+    pos, spin = random_state(rng, par.L, N, par.K)
+    orc = so.SyncOracle(par, dt=0.03, seed=99)
+    orc.set_state(pos, spin)
+    h = make_handle(capi, par, N, dt=0.03, seed=99, method="lattice")
+    try:
+        h.set_state(pos, spin)
+        h.step(3)                               # odd start: one single step precedes the first replay
+        h.step(300)
+        h.step(41)
+        orc.run(344)
+        p, sg, bd, al = h.get_state()
+        assert np.array_equal(al, orc.alive) and np.array_equal(p, orc.pos)
+        assert np.array_equal(sg, orc.spin) and np.array_equal(bd, orc.bound)
+        assert h.time()[1] == 344
+        ex, ex0 = h.exits(), orc.exits()
+        assert len(ex) == len(ex0)
+        if len(ex0):
+            assert np.array_equal(ex, ex0[np.lexsort((ex0[:, 2], ex0[:, 0]))])
+        check_lattice(h, orc)
+    finally:
+        h.close()
