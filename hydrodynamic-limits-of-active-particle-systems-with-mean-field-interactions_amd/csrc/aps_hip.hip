@@ -844,135 +844,207 @@ __global__ __launch_bounds__(256) void propose_lattice(const LatticeArgs a) {
     }
 }
 
-// field_update: one workgroup owns 256 * R consecutive sites (lane = R sites, 256 apart) and adds every deposit
-// in reach to them.  The deposits sit in per-bucket lists (bucket = B consecutive sites of the depositing
-// particle's old position); the workgroup copies the lists of the buckets in reach into LDS (counts -> scan ->
-// copy, 8 threads per bucket) and all waves then sweep that list: the deposit is wave-uniform (scalar
-// registers), so the 64 lanes read 64 CONSECUTIVE table entries -- a conflict-free ds_read_b64 -- and issue two
-// f64 fma's (W and S).  Nobody else writes these sites: plain read-modify-write at the end, no atomics.
-constexpr int FU_THREADS = 256, FU_LIST = 2048;
-struct FieldUpdArgs { int L, tlen, bshift, nb, dcap; double2 *ws; const uint32_t *dcnt, *dep; };
+// field_update: one workgroup owns SITES = 64 * RS consecutive sites and adds every deposit in reach to them.
+// The deposits sit in per-bucket lists (bucket = B consecutive sites of the depositing particle's old position).
+// The four waves SPLIT THE BUCKETS in reach (dealt round-robin): a wave fetches 8 list slots of 8 buckets per load
+// (lane = (bucket, slot)), together with the buckets' counters, compacts the valid ones into its own LDS segment (ballot + mbcnt)
+// and sweeps ALL the workgroup's sites with them (lane = RS sites, 64 apart).  A deposit is wave-uniform (scalar
+// registers), so the 64 lanes read 64 CONSECUTIVE table entries -- a conflict-free ds_read_b64 -- and issue two f64
+// fma's (W and S); the LDS copy of the table is zero-padded so that interior workgroups need no range clamp.  The
+// four partial sums per site are added through LDS (exact on the weight grid, any order) and each site is
+// updated by exactly one thread: plain read-modify-write, no atomics.  Counters, list slots, table and the sites'
+// old values are all requested up front: the kernel pays ONE memory round trip before it computes.
+constexpr int FU_THREADS = 256, FU_WAVES = FU_THREADS / 64, FU_SEG = 256, FU_TREG = 16, FU_PRE = 2;
+struct FieldUpdArgs { int L, tlen, bshift, nb, dcap; double2 *ws; const uint32_t *dcnt, *dep; unsigned long long *stamps; };
 
-__host__ __device__ inline size_t fu_lds_bytes(int tlen, bool tab_lds) {
-    return lds_table_bytes(tlen, tab_lds) + (size_t)(FU_LIST + 4 + 256 + 256 + 8) * sizeof(uint32_t);
+__host__ __device__ inline int fu_table_pad(int RS, int bshift) { return 64 * RS + (1 << bshift) + 2; }
+__host__ __device__ inline size_t fu_lds_bytes(int tlen, bool tab_lds, int RS, int bshift) {
+    const size_t table = tab_lds ? ((size_t)tlen + 2 + fu_table_pad(RS, bshift)) / 2 * 2 * sizeof(double) : 0;
+    const size_t red = (size_t)FU_WAVES * 64 * RS * sizeof(double2);          // reuses the table's space after the sweep
+    return (size_t)FU_WAVES * 2 * (FU_SEG + 4) * sizeof(uint32_t) + (table > red ? table : red);
 }
 
-template <int VAR, bool TAB_LDS, int R>   // VAR: 0 = interior (no image term), 1 = torus, 2 = reflecting wall in reach
-__device__ __forceinline__ void fu_entry(const uint32_t ent_v, const uint32_t (&x8)[R], const uint32_t tbase, const double *__restrict__ table_g,
-                                         const uint32_t tlen8, const uint32_t L8, double (&accW)[R], double (&accS)[R]) {
-    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent_v);      // wave-uniform: decode on the scalar unit
-    const uint32_t p8 = (ent & POS_MASK) << 3;
-    const double cw = (double)((int)((ent >> 27) & 3u) - 1), cs = (double)((int)(ent >> 29) - 2);
+// VAR: 0 = interior (no image term, padded table: no clamp), 1 = torus, 2 = reflecting wall in reach
+template <int VAR, bool TAB_LDS, int RS>
+__device__ __forceinline__ void fu_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase, const double *__restrict__ table_g,
+                                         const uint32_t tlen8, const uint32_t L8, double (&accW)[RS], double (&accS)[RS]) {
+    const uint32_t ent[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
+    double w[4][RS];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        double w;
-        if (VAR == 0) {
-            w = table_at<TAB_LDS>(table_g, min(sad3(x8[r], p8, tbase), tlen8 + tbase));
-        } else if (VAR == 1) {
-            const uint32_t d8 = sad3(x8[r], p8, 0u);
-            w = table_at<TAB_LDS>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
-        } else {
-            const uint32_t s8 = x8[r] + p8 + 8u;
-            w = table_at<TAB_LDS>(table_g, min(sad3(x8[r], p8, 0u), tlen8) + tbase);
-            w += table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
+    for (int k = 0; k < 4; ++k) {                            // wave-uniform deposit: decode on the scalar unit
+        const uint32_t p8 = (ent[k] & POS_MASK) << 3;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (VAR == 0) {
+                const uint32_t d = sad3(x8[r], p8, tbase);
+                w[k][r] = table_at<TAB_LDS>(table_g, TAB_LDS ? d : min(d, tlen8));
+            } else if (VAR == 1) {
+                const uint32_t d8 = sad3(x8[r], p8, 0u);
+                w[k][r] = table_at<TAB_LDS>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
+            } else {
+                const uint32_t s8 = x8[r] + p8 + 8u;
+                w[k][r] = table_at<TAB_LDS>(table_g, min(sad3(x8[r], p8, 0u), tlen8) + tbase) +
+                          table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
+            }
         }
-        accW[r] = fma(w, cw, accW[r]);                       // cw, cs in {-2..2}: exact on the weight grid
-        accS[r] = fma(w, cs, accS[r]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double cw = (double)((int)((ent[k] >> 27) & 3u) - 1), cs = (double)((int)(ent[k] >> 29) - 2);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            accW[r] = fma(w[k][r], cw, accW[r]);             // cw, cs in {-2..2}: exact on the weight grid
+            accS[r] = fma(w[k][r], cs, accS[r]);
+        }
     }
 }
 
-template <int BC, bool TAB_LDS, int R>
+template <int BC, bool TAB_LDS, int RS>
 __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a, const double *__restrict__ table_g) {
+    constexpr int SITES = 64 * RS, NOLD = (SITES + FU_THREADS - 1) / FU_THREADS;
     extern __shared__ double lds[];
-    uint32_t *list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + lds_table_bytes(a.tlen, TAB_LDS));
-    uint32_t *bc = list + FU_LIST + 4, *bo = bc + 256, *wtot = bo + 256;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, e = blockIdx.y;
-    const int L = a.L, x0 = blockIdx.x * FU_THREADS * R, x1 = min(x0 + FU_THREADS * R - 1, L - 1);
+    const int tpad = TAB_LDS ? a.tlen + fu_table_pad(RS, a.bshift) : 0;        // last LDS table index (zeros beyond tlen - 1)
+    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds);                   // [FU_WAVES][2][FU_SEG + 4] deposits, then the table
+    double *tab = reinterpret_cast<double *>(seg_all + FU_WAVES * 2 * (FU_SEG + 4));
+    double2 *red = reinterpret_cast<double2 *>(tab);          // [FU_WAVES][SITES] partial sums, over the table once it is no longer read
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
+    uint32_t *seg = seg_all + wave * 2 * (FU_SEG + 4), *segi = seg + FU_SEG + 4;   // plain deposits / deposits with an image term
+    const int L = a.L, x0 = blockIdx.x * SITES, x1 = min(x0 + SITES - 1, L - 1);
     const int Rt = a.tlen - 1;                                // largest distance with a non-zero weight
-    // buckets whose deposits can reach [x0, x1]: deposit sites lie within one site of their bucket
-    int rlo[2], rhi[2], nr = 1;
+#ifdef APS_STAMPS
+    unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long f_start = t0, r_start = __builtin_amdgcn_s_memrealtime();
+#define FSTAMP(var) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - t0; t0 = t1_; }
+#else
+#define FSTAMP(var)
+#endif
+    // buckets whose deposits can reach [x0, x1] (deposit sites lie within one site of their bucket), as one run of
+    // `nbk` buckets starting at `b0` that may wrap around the torus
+    int b0, nbk;
     if (BC == 0) {
-        rlo[0] = max(0, x0 - Rt - 1) >> a.bshift; rhi[0] = min(L - 1, x1 + Rt + 1) >> a.bshift;
+        b0 = max(0, x0 - Rt - 1) >> a.bshift;
+        nbk = (min(L - 1, x1 + Rt + 1) >> a.bshift) - b0 + 1;
     } else {
         const int lo = x0 - Rt - 1, hi = x1 + Rt + 1;
-        if (hi - lo + 1 >= L) { rlo[0] = 0; rhi[0] = a.nb - 1; }
-        else if (lo >= 0 && hi < L) { rlo[0] = lo >> a.bshift; rhi[0] = hi >> a.bshift; }
+        if (hi - lo + 1 >= L) { b0 = 0; nbk = a.nb; }
         else {
-            const int h1 = lo < 0 ? hi : hi - L, l2 = lo < 0 ? lo + L : lo;     // [0, h1] and [l2, L-1]
-            rlo[0] = 0; rhi[0] = h1 >> a.bshift; rlo[1] = l2 >> a.bshift; rhi[1] = a.nb - 1; nr = 2;
-            if (rlo[1] <= rhi[0]) { rhi[0] = a.nb - 1; nr = 1; }
+            const int blo = (lo < 0 ? lo + L : lo) >> a.bshift, bhi = (hi >= L ? hi - L : hi) >> a.bshift;
+            b0 = blo;
+            nbk = (lo >= 0 && hi < L) ? bhi - blo + 1 : (a.nb - blo) + bhi + 1;
+            if (nbk > a.nb) { b0 = 0; nbk = a.nb; }
         }
     }
     const bool wall = BC == 0 && ((x0 + 1 <= Rt) || (L - x1 <= Rt));   // an image term can be non-zero
+    // Requests that depend on nothing: counters and first list slots of the first FU_PRE bucket groups (a group =
+    // 32 buckets, 8 per wave, 8 slots each), the table, the sites' old values.
+    const int sub = lane >> 3, slot = lane & 7;
+    uint32_t pre_cnt[FU_PRE], pre_ent[FU_PRE];
+#pragma unroll
+    for (int j = 0; j < FU_PRE; ++j) {
+        const int bi = j * 32 + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
+        int b = b0 + bi;
+        if (b >= a.nb) b -= a.nb;
+        const bool ok = bi < nbk;
+        pre_cnt[j] = ok ? a.dcnt[(size_t)e * a.nb + b] : 0u;
+        pre_ent[j] = (ok && slot < a.dcap) ? a.dep[((size_t)e * a.nb + b) * a.dcap + slot] : DEP_NULL;
+    }
+    double tv[FU_TREG];
+    if (TAB_LDS) {
+#pragma unroll
+        for (int u = 0; u < FU_TREG; ++u) { const int i = t + u * FU_THREADS; tv[u] = i < a.tlen ? table_g[i] : 0.0; }
+    }
+    double2 old[NOLD];
+#pragma unroll
+    for (int r = 0; r < NOLD; ++r) {
+        const int xi = r * FU_THREADS + t, x = x0 + xi;
+        old[r] = (xi < SITES && x < L) ? a.ws[(size_t)e * L + x] : make_double2(0.0, 0.0);
+    }
     uint32_t tbase = 0;
     if (TAB_LDS) {
         typedef __attribute__((address_space(3))) double lds_double;
-        tbase = (uint32_t)(size_t)(lds_double *)lds;
+        tbase = (uint32_t)(size_t)(lds_double *)tab;
+#pragma unroll
+        for (int u = 0; u < FU_TREG; ++u) { const int i = t + u * FU_THREADS; if (i <= tpad) tab[i] = tv[u]; }
+        for (int i = t + FU_TREG * FU_THREADS; i <= tpad; i += FU_THREADS) tab[i] = i < a.tlen ? table_g[i] : 0.0;   // beyond 4096 entries
     }
     const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)L << 3;
-    uint32_t x8[R];
-    double accW[R], accS[R];
+    uint32_t x8[RS];
+    double accW[RS], accS[RS];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { x8[r] = (uint32_t)min(x0 + r * FU_THREADS + t, L - 1) << 3; accW[r] = accS[r] = 0.0; }
-    bool staged = false, touched = false;
-    for (int ri = 0; ri < nr; ++ri)
-        for (int cb = rlo[ri]; cb <= rhi[ri]; cb += 256) {
-            const int nbk = min(256, rhi[ri] - cb + 1);
-            const uint32_t c = t < nbk ? min(a.dcnt[(size_t)e * a.nb + cb + t], (uint32_t)a.dcap) : 0u;
-            uint32_t v = c;                                   // inclusive scan over the workgroup
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t n = __shfl_up(v, off); if (lane >= off) v += n; }
-            if (lane == 63) wtot[wave] = v;
-            __syncthreads();
-            uint32_t before = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < FU_THREADS / 64; ++w) { const uint32_t s = wtot[w]; total += s; if (w < wave) before += s; }
-            bc[t] = c; bo[t] = before + v - c;
-            __syncthreads();
-            if (total == 0) continue;                         // uniform
-            touched = true;
-            if (TAB_LDS && !staged) { stage_table(lds, table_g, a.tlen); staged = true; }
-            for (uint32_t w0 = 0; w0 < total; w0 += FU_LIST) {
-                const uint32_t wn = min((uint32_t)FU_LIST, total - w0);
-                for (int bi = t >> 3; bi < nbk; bi += FU_THREADS / 8) {       // 8 threads copy one bucket's list
-                    const uint32_t cnt = bc[bi], off = bo[bi];
-                    const uint32_t *from = a.dep + ((size_t)e * a.nb + cb + bi) * a.dcap;
-                    for (uint32_t k = t & 7; k < cnt; k += 8) {
-                        const uint32_t pos = off + k - w0;    // unsigned: entries before the window wrap to huge
-                        if (pos < wn) list[pos] = from[k];
-                    }
-                }
-                if (t < 4) list[wn + t] = DEP_NULL;           // pad to whole groups of four
-                __syncthreads();
-                const uint4 *list4 = reinterpret_cast<const uint4 *>(list);
-                const int n4 = (int)((wn + 3) >> 2);
+    for (int r = 0; r < RS; ++r) { x8[r] = (uint32_t)min(x0 + r * 64 + lane, L - 1) << 3; accW[r] = accS[r] = 0.0; }
+    __syncthreads();                                          // table staged
+    FSTAMP(f_stage)
+    int nseg = 0, nimg = 0;                                   // entries waiting in this wave's two segments
+    const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg), *segi4 = reinterpret_cast<const uint4 *>(segi);
+    auto flush = [&]() {                                      // sweep all SITES with the segments' deposits
+        if (lane < 4) { seg[nseg + lane] = DEP_NULL | (uint32_t)x0; segi[nimg + lane] = DEP_NULL | (uint32_t)x0; }   // pad to groups of four (a site of this tile: in table range)
+        const int n4 = (nseg + 3) >> 2, ni4 = (nimg + 3) >> 2;
 #pragma unroll 1
-                for (int i = 0; i < n4; ++i) {
-                    const uint4 q = list4[i];                 // uniform address: LDS broadcast
-                    if (BC == 1) {
-                        fu_entry<1, TAB_LDS, R>(q.x, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<1, TAB_LDS, R>(q.y, x8, tbase, table_g, tlen8, L8, accW, accS);
-                        fu_entry<1, TAB_LDS, R>(q.z, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<1, TAB_LDS, R>(q.w, x8, tbase, table_g, tlen8, L8, accW, accS);
-                    } else if (wall) {
-                        fu_entry<2, TAB_LDS, R>(q.x, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<2, TAB_LDS, R>(q.y, x8, tbase, table_g, tlen8, L8, accW, accS);
-                        fu_entry<2, TAB_LDS, R>(q.z, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<2, TAB_LDS, R>(q.w, x8, tbase, table_g, tlen8, L8, accW, accS);
-                    } else {
-                        fu_entry<0, TAB_LDS, R>(q.x, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<0, TAB_LDS, R>(q.y, x8, tbase, table_g, tlen8, L8, accW, accS);
-                        fu_entry<0, TAB_LDS, R>(q.z, x8, tbase, table_g, tlen8, L8, accW, accS); fu_entry<0, TAB_LDS, R>(q.w, x8, tbase, table_g, tlen8, L8, accW, accS);
-                    }
-                }
-                __syncthreads();                              // the list is rewritten by the next window / chunk
-            }
+        for (int i = 0; i < n4; ++i) {
+            const uint4 q = seg4[i];                          // uniform address: LDS broadcast
+            if (BC == 1) fu_group<1, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
+            else fu_group<0, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
         }
-    if (!touched) return;                                     // nothing in reach (uniform)
+#pragma unroll 1
+        for (int i = 0; i < ni4; ++i) fu_group<2, TAB_LDS, RS>(segi4[i], x8, tbase, table_g, tlen8, L8, accW, accS);
+#ifdef APS_STAMPS
+        f_n += nseg + nimg;
+#endif
+        nseg = nimg = 0;
+    };
+    const int ngroups = (nbk + 31) >> 5;
+    for (int j = 0; j < ngroups; ++j) {
+        const int bi = j * 32 + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
+        int b = b0 + bi;
+        if (b >= a.nb) b -= a.nb;
+        const bool ok = bi < nbk;
+        uint32_t cnt, ent;
+        if (j < FU_PRE) { cnt = j == 0 ? pre_cnt[0] : pre_cnt[FU_PRE - 1]; ent = j == 0 ? pre_ent[0] : pre_ent[FU_PRE - 1]; }
+        else {
+            cnt = ok ? a.dcnt[(size_t)e * a.nb + b] : 0u;
+            ent = (ok && slot < a.dcap) ? a.dep[((size_t)e * a.nb + b) * a.dcap + slot] : DEP_NULL;
+        }
+        cnt = min(cnt, (uint32_t)a.dcap);
+        for (uint32_t k0 = 0;; k0 += 8) {                     // 8 slots of the wave's 8 buckets per round
+            const bool valid = k0 + slot < cnt;
+            // near a reflecting wall only some deposits have an image in reach: x + p + 1 <= Rt or 2L - 1 - x - p <= Rt
+            const int dp = (int)(ent & POS_MASK);
+            const bool img = valid && wall && ((x0 + dp + 1 <= Rt) || (2 * L - 1 - x1 - dp <= Rt));
+            const unsigned long long m = __ballot(valid && !img), mi = __ballot(img);
+            if (nseg + 64 > FU_SEG || nimg + 64 > FU_SEG) flush();
+            if (valid && !img) seg[nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = ent;
+            if (img) segi[nimg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u))] = ent;
+            nseg += __popcll(m); nimg += __popcll(mi);
+            if (!__ballot(k0 + 8 < cnt)) break;               // no bucket of this wave has more
+            ent = (k0 + 8 + slot < cnt) ? a.dep[((size_t)e * a.nb + b) * a.dcap + k0 + 8 + slot] : DEP_NULL;
+        }
+    }
+    FSTAMP(f_copy)
+    flush();
+    FSTAMP(f_proc)
+    __syncthreads();                                          // every wave is done with the table: its space takes the partial sums
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int x = x0 + r * FU_THREADS + t;
-        if (x < L) {
-            double2 f = a.ws[(size_t)e * L + x];
-            f.x += accW[r]; f.y += accS[r];
+    for (int r = 0; r < RS; ++r) red[(size_t)wave * SITES + r * 64 + lane] = make_double2(accW[r], accS[r]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NOLD; ++r) {
+        const int xi = r * FU_THREADS + t, x = x0 + xi;
+        if (xi < SITES && x < L) {
+            double2 f = old[r];
+#pragma unroll
+            for (int w = 0; w < FU_WAVES; ++w) { const double2 pth = red[(size_t)w * SITES + xi]; f.x += pth.x; f.y += pth.y; }
             a.ws[(size_t)e * L + x] = f;
         }
     }
+#ifdef APS_STAMPS
+    FSTAMP(f_cnt)
+    if (t == 0 && a.stamps && blockIdx.x < 4096) {
+        unsigned long long *o = a.stamps + (size_t)blockIdx.x * 8;
+        o[0] = f_cnt; o[1] = f_stage; o[2] = f_copy; o[3] = f_proc; o[4] = __builtin_amdgcn_s_memtime() - f_start;
+        o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = r_start; o[7] = f_n;
+    }
+#endif
 }
 
 // Rate vectors of step_gillespie (ref :254-352) for caller-supplied particles, m-field and site histograms:
@@ -1086,6 +1158,7 @@ struct aps_handle {
     uint32_t *d_dcnt = nullptr, *d_dep = nullptr;
     unsigned long long *d_stepw = nullptr;     // [2] device step words
     int bshift = 8, nb = 0, dcap = 0, fu_R = 1;
+    bool fu_table_in_lds = true;
     bool field_dirty = true;
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -1347,10 +1420,13 @@ int set_lds_limit(aps_handle *h) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_sites<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, n));
     }
-    if (h->table_in_lds && fu_lds_bytes(h->tlen, true) > 48 * 1024) {
-        const int n = (int)fu_lds_bytes(h->tlen, true);
-#define APS_ATTR(BC, RR) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_update<BC, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, n))
-        APS_ATTR(0, 1); APS_ATTR(0, 2); APS_ATTR(0, 4); APS_ATTR(1, 1); APS_ATTR(1, 2); APS_ATTR(1, 4);
+    h->fu_table_in_lds = fu_lds_bytes(h->tlen, true, h->fu_R, h->bshift) <= 160 * 1024;
+    if (fu_lds_bytes(h->tlen, h->fu_table_in_lds, h->fu_R, h->bshift) > 48 * 1024) {
+        const int n = (int)fu_lds_bytes(h->tlen, h->fu_table_in_lds, h->fu_R, h->bshift);
+#define APS_ATTR(BC, TL, RR) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&field_update<BC, TL, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, n))
+#define APS_ATTR4(BC, TL) APS_ATTR(BC, TL, 2); APS_ATTR(BC, TL, 3); APS_ATTR(BC, TL, 4); APS_ATTR(BC, TL, 5); APS_ATTR(BC, TL, 6); APS_ATTR(BC, TL, 7); APS_ATTR(BC, TL, 8)
+        if (h->fu_table_in_lds) { APS_ATTR4(0, true); APS_ATTR4(1, true); } else { APS_ATTR4(0, false); APS_ATTR4(1, false); }
+#undef APS_ATTR4
 #undef APS_ATTR
     }
     hipDeviceProp_t prop;
@@ -1447,14 +1523,15 @@ int launch_field_update(aps_handle *h) {
     if (!h->model.field_mode) return APS_OK;
     int rc = prof_mark(h, KIND_FIELD_UPDATE);
     if (rc) return rc;
-    FieldUpdArgs f{h->p.L, h->tlen, h->bshift, h->nb, h->dcap, h->d_ws, h->d_dcnt, h->d_dep};
-    const int R = h->fu_R;
-    const dim3 grid((unsigned)((h->p.L + FU_THREADS * R - 1) / (FU_THREADS * R)), (unsigned)h->E), block(FU_THREADS);
-    const size_t lds = fu_lds_bytes(h->tlen, h->table_in_lds);
+    FieldUpdArgs f{h->p.L, h->tlen, h->bshift, h->nb, h->dcap, h->d_ws, h->d_dcnt, h->d_dep, h->d_stamps};
+    const int RS = h->fu_R;
+    const dim3 grid((unsigned)((h->p.L + 64 * RS - 1) / (64 * RS)), (unsigned)h->E), block(FU_THREADS);
+    const size_t lds = fu_lds_bytes(h->tlen, h->fu_table_in_lds, RS, h->bshift);
 #define APS_FU(BC, TL, RR) hipLaunchKernelGGL((field_update<BC, TL, RR>), grid, block, lds, h->stream, f, h->d_table)
-#define APS_FU_R(BC, TL) do { if (R == 4) APS_FU(BC, TL, 4); else if (R == 2) APS_FU(BC, TL, 2); else APS_FU(BC, TL, 1); } while (0)
-    if (h->p.periodic) { if (h->table_in_lds) APS_FU_R(1, true); else APS_FU_R(1, false); }
-    else { if (h->table_in_lds) APS_FU_R(0, true); else APS_FU_R(0, false); }
+#define APS_FU_R(BC, TL) do { switch (RS) { case 8: APS_FU(BC, TL, 8); break; case 7: APS_FU(BC, TL, 7); break; case 6: APS_FU(BC, TL, 6); break; \
+        case 5: APS_FU(BC, TL, 5); break; case 4: APS_FU(BC, TL, 4); break; case 3: APS_FU(BC, TL, 3); break; default: APS_FU(BC, TL, 2); } } while (0)
+    if (h->p.periodic) { if (h->fu_table_in_lds) APS_FU_R(1, true); else APS_FU_R(1, false); }
+    else { if (h->fu_table_in_lds) APS_FU_R(0, true); else APS_FU_R(0, false); }
 #undef APS_FU_R
 #undef APS_FU
     HIP_TRY(h, hipGetLastError());
@@ -1558,9 +1635,17 @@ int aps_create(const aps_params *p, aps_handle **out) {
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "pairs")) h->method = APS_METHOD_PAIRS;
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "lattice")) h->method = APS_METHOD_LATTICE;
         }
-        const int64_t blocks1 = ((int64_t)p->L + FU_THREADS - 1) / FU_THREADS * h->E;   // sites per lane so that the grid still fills the chip
-        h->fu_R = blocks1 >= 4 * 1024 ? 4 : (blocks1 >= 2 * 384 ? 2 : 1);
-        if (const char *env = std::getenv("APS_FU_R")) { const int r = std::atoi(env); if (r == 1 || r == 2 || r == 4) h->fu_R = r; }
+        // sites per lane of field_update: the largest tile that still gives about two workgroups per CU
+        // sites per lane of field_update (tile = 64 * RS sites per workgroup): about 2.4 workgroups per CU was the
+        // fastest grid on MI355X (measured, RS = 5 at L = 2e5); large lattices take the largest tile (fewest table copies)
+        h->fu_R = 2;
+        double best = 1e300;
+        for (int rs : {2, 3, 4, 5, 6, 7, 8}) {
+            const double wgs = (double)(((int64_t)p->L + 64 * rs - 1) / (64 * rs)) * h->E;
+            const double miss = std::fabs(wgs - 2.4 * 256.0);
+            if (miss < best) { best = miss; h->fu_R = rs; }
+        }
+        if (const char *env = std::getenv("APS_FU_R")) { const int r = std::atoi(env); if (r >= 2 && r <= 8) h->fu_R = r; }
     }
     // A particle moves at most one site per step, so tile bounds drift by <= 1 per step: when nobody can die
     // (has-dead flags are then static) or wrap around, a plan with a 16-site margin serves 8 steps.
