@@ -46,7 +46,7 @@ def lattice_algo_bytes(kernel, N, L, changed, deposits):
 
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
 LDS_CYCLES_PER_64_PAIRS = 5.0  # measured (PMC 4.93): 4.5 per table gather (2.0 + 2.5 bank conflicts) + 0.5 source broadcast
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 FETCH_SIZE/WRITE_SIZE of this command
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_lattice_pmc_traffic.json")   # rocprofv3 FETCH_SIZE/WRITE_SIZE of this command
 
 
 def measured_traffic_bytes(kernel="pair_accumulate"):
@@ -135,8 +135,8 @@ class stdout_to_stderr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2"] + sorted(EXTRA))
     ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs"])
@@ -232,7 +232,9 @@ def main():
             ms_fu, n_fu, deposits = h.step_timed(reps)            # deposits = field changes of the sampled steps
             after = h.get_state()
             prof = h.step_profile(reps)
-            kern = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}          # seconds per launch
+            ev_over = h.event_overhead() * 1e-3                   # what an empty event bracket reads (s)
+            raw = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}           # seconds per launch, as bracketed
+            kern = raw                                            # reported as bracketed (conservative: includes ~2 us of event cost)
             dep_per_step = deposits / max(n_fu, 1)
             changed_per_step = 0.6 * dep_per_step                 # a hop makes 2 deposits, a flip 1 (about half each)
             N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
@@ -243,6 +245,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(dom),
                     "avg_launch_us": kern[dom] * 1e6, "algorithmic_bytes_per_launch": algo[dom],
+                    "event_pair_overhead_us": ev_over * 1e6,
                     "per_kernel": {k: {"avg_launch_us": kern[k] * 1e6, "algorithmic_bytes_per_launch": algo[k],
                                        "achieved_GBps": algo[k] / kern[k] / 1e9, "traffic": measured_traffic_bytes(k)} for k in kern},
                     "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step_graph_replay": elapsed / args.steps * 1e6,

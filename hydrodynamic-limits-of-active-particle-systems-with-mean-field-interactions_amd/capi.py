@@ -104,6 +104,7 @@ def load():
         "aps_lattice_accumulate": (C.c_int, [vp, i32, vp, vp, vp, i64]),
         "aps_get_lattice": (C.c_int, [vp, i32, vp, vp, vp]),
         "aps_method": (C.c_int, [vp]),
+        "aps_event_overhead": (C.c_int, [vp, i32, P(dbl)]),
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
@@ -237,6 +238,12 @@ class Handle:
         ms, cnt = np.zeros(len(KERNELS)), np.zeros(len(KERNELS), np.int64)
         self._ck(self.lib.aps_step_profile(self._h, int(nsteps), _ptr(ms), _ptr(cnt)))
         return {k: (float(m), int(c)) for k, m, c in zip(KERNELS, ms, cnt)}
+
+    def event_overhead(self, reps=50):
+        """Elapsed time (ms) the HIP events report for an empty bracket on the handle's stream."""
+        ms = C.c_double()
+        self._ck(self.lib.aps_event_overhead(self._h, int(reps), C.byref(ms)))
+        return ms.value
 
     # -- observation
     def observe(self, ensemble=0, want_field=True):

@@ -1828,6 +1828,7 @@ int build_graph(aps_handle *h) {
     const int64_t step0 = h->step;
     HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     h->stream = h->cap_stream;
+    h->step = 0;                                             // only the parity is baked in: replays start on even steps
     int rc = APS_OK;
     for (int k = 0; k < GRAPH_STEPS && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
     h->stream = user_stream;
@@ -1905,10 +1906,10 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     if (rc) return rc;
     int64_t s = 0;
     static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
-    if (h->method == APS_METHOD_LATTICE && h->world == 1 && !no_graph && nsteps >= GRAPH_STEPS + 1) {
-        if (h->step & 1) { if ((rc = one_step(h))) return rc; ++s; }       // the graph starts on an even step
-        if ((rc = build_graph(h))) return rc;
-        for (; nsteps - s >= h->graph_steps; s += h->graph_steps) {
+    if (h->method == APS_METHOD_LATTICE && h->world == 1 && !no_graph && nsteps > 0) {
+        if ((rc = build_graph(h))) return rc;                              // once per handle, on the first stepping call
+        if ((h->step & 1) && nsteps - s > h->graph_steps) { if ((rc = one_step(h))) return rc; ++s; }   // replays start on even steps
+        for (; !(h->step & 1) && nsteps - s >= h->graph_steps; s += h->graph_steps) {
             HIP_TRY(h, hipGraphLaunch(h->gexec, h->stream));
             h->step += h->graph_steps;
         }
@@ -1946,6 +1947,23 @@ int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launch
 }
 
 int aps_method(aps_handle *h) { return h ? h->method : APS_ERR_ARG; }
+
+int aps_event_overhead(aps_handle *h, int32_t reps, double *ms_per_pair) {
+    if (!h || !ms_per_pair || reps < 1) return APS_ERR_ARG;
+    while ((int64_t)h->events.size() < 2) { hipEvent_t ev; HIP_TRY(h, hipEventCreate(&ev)); h->events.push_back(ev); }
+    double total = 0.0;
+    for (int r = 0; r < reps; ++r) {                        // two events recorded back to back on an idle stream
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipEventRecord(h->events[0], h->stream));
+        HIP_TRY(h, hipEventRecord(h->events[1], h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        float t = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&t, h->events[0], h->events[1]));
+        total += t;
+    }
+    *ms_per_pair = total / reps;
+    return APS_OK;
+}
 
 int aps_lattice_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t *occ4, int64_t n) {
     if (!h) return APS_ERR_ARG;

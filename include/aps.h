@@ -151,6 +151,10 @@ int aps_resort(aps_handle *h);
  * their summed duration, the number of launches and the work done: pair evaluations (PAIRS) or deposits (LATTICE). */
 int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *launches, double *work);
 
+/* What the instrument itself reads: mean elapsed time between two events recorded back to back (nothing in between)
+ * on the handle's stream.  Event-bracketed durations of microsecond kernels carry this offset. */
+int aps_event_overhead(aps_handle *h, int32_t reps, double *ms_per_pair);
+
 /* The same for every kernel of the step: ms7[k] / launches7[k] summed over nsteps, k = pair_accumulate, propose,
  * claim, apply, plan_tiles, propose_lattice, field_update. */
 int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launches7);

@@ -3,7 +3,7 @@ Usage: python tools/summarize_pmc.py out.json dir_or_csv [dir_or_csv ...]"""
 import collections, csv, glob, json, os, re, sys
 
 def short(name):
-    m = re.search(r"(pair_accumulate|plan_tiles|propose|apply|claim|field_sites)", name)
+    m = re.search(r"(pair_accumulate|plan_tiles|propose_lattice|field_update|propose|apply|claim|field_sites)", name)
     return m.group(1) if m else name.split("(")[0][:40]
 
 out = collections.defaultdict(dict)
@@ -22,4 +22,4 @@ json.dump({"note": "rocprofv3 --pmc, separate passes per counter group, mean per
                    "MI355X_MICROARCH.md gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x "
                    "(these kernels issue 4-byte-per-lane loads: uncalibrated).",
            "per_dispatch": out}, open(sys.argv[1], "w"), indent=1, sort_keys=True)
-print(json.dumps(out.get("pair_accumulate", {}), indent=1))
+print(json.dumps({k: out[k] for k in ("pair_accumulate", "field_update", "propose_lattice", "apply") if k in out}, indent=1))
