@@ -104,6 +104,8 @@ def load():
         "aps_lattice_accumulate": (C.c_int, [vp, i32, vp, vp, vp, i64]),
         "aps_get_lattice": (C.c_int, [vp, i32, vp, vp, vp]),
         "aps_method": (C.c_int, [vp]),
+        "aps_mark_reference": (C.c_int, [vp, i32]),
+        "aps_observe_scalars": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
         "aps_event_overhead": (C.c_int, [vp, i32, P(dbl)]),
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
@@ -244,6 +246,21 @@ class Handle:
         ms = C.c_double()
         self._ck(self.lib.aps_event_overhead(self._h, int(reps), C.byref(ms)))
         return ms.value
+
+    SCALARS = ("n", "sum_sigma", "sum_pos", "n_wall", "max_pos", "n_range", "attempts", "blocked", "sum_d", "sum_d2", "n_d")
+
+    def mark_reference(self, ensemble=0):
+        """Remember the current positions of ensemble `ensemble` as the origin of the displacement sums."""
+        self._ck(self.lib.aps_mark_reference(self._h, ensemble))
+
+    def observe_scalars(self, ensemble=0, x_wall=0, range_lo=0, range_hi=-1, block_table=None):
+        """Integer sums over the live particles (see include/aps.h) as a dict of Python ints."""
+        out = np.zeros(len(self.SCALARS), np.int64)
+        tab = None if block_table is None else np.ascontiguousarray(block_table, dtype=np.uint8)
+        if tab is not None and tab.size != (self.K + 1) ** 2:
+            raise ValueError("block_table must have (K+1)*(K+1) entries")
+        self._ck(self.lib.aps_observe_scalars(self._h, ensemble, int(x_wall), int(range_lo), int(range_hi), _ptr(tab), _ptr(out)))
+        return {k: int(v) for k, v in zip(self.SCALARS, out)}
 
     # -- observation
     def observe(self, ensemble=0, want_field=True):

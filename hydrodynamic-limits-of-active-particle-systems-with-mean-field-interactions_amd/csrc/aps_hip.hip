@@ -1112,6 +1112,69 @@ __global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const
     a.m_out[x] = mloc;
 }
 
+// Driver-side observables: the integer sums from which the sweep drivers' statistics are built
+// (compute_v_eff_and_window, compute_blocking_probability, compute_mean_magnetizatoin, compute_D_eff_active,
+// PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py:123-229, :316-319, :500-525), taken on the device so that a sweep
+// needs no M x L density arrays.  All outputs are exact integers; the float formulas stay on the host.
+struct ScalarArgs {
+    const uint32_t *src, *orig, *occ_site;   // occ_site may be null (all-pairs formulation): occupancy from counts array
+    const uint32_t *ref;                     // [Npad] packed reference state by slot, or null
+    const uint8_t *block_table;              // [(K+1)*(K+1)]: is a right neighbour holding (plus, minus) particles "blocking"?
+    const uint32_t *cnt_pm;                  // [L] per-site counts plus | minus << 16 (built by count_sites)
+    long long *out;                          // [16]
+    int Npad, L, K, x_wall, lo, hi;
+};
+enum { SC_N = 0, SC_SPIN, SC_POS, SC_WALL, SC_MAXPOS, SC_RANGE, SC_ATTEMPT, SC_BLOCKED, SC_DISP, SC_DISP2, SC_NDISP, SC_COUNT };
+
+__global__ __launch_bounds__(256) void count_sites(const uint32_t *__restrict__ src, uint32_t *cnt_pm, int Npad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Npad) return;
+    const uint32_t w = src[i];
+    if (w & DEAD_BIT) return;
+    atomicAdd(&cnt_pm[w & POS_MASK], (w & SPIN_BIT) ? 1u : 65536u);
+}
+
+__device__ inline long long wave_sum(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
+    long long v[SC_COUNT] = {0, 0, 0, 0, -1, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.Npad; i += gridDim.x * blockDim.x) {
+        const uint32_t w = a.src[i];
+        if (w & DEAD_BIT) continue;
+        const int p = (int)(w & POS_MASK);
+        const bool plus = (w & SPIN_BIT) != 0;
+        v[SC_N] += 1; v[SC_SPIN] += plus ? 1 : -1; v[SC_POS] += p;
+        v[SC_WALL] += p >= a.x_wall;
+        v[SC_MAXPOS] = max(v[SC_MAXPOS], (long long)p);
+        v[SC_RANGE] += (p >= a.lo && p <= a.hi);
+        if (plus && p < a.L - 1) {                            // ref :197-229: movers on sites 0..L-2, blocked by the right neighbour
+            const uint32_t c = a.cnt_pm[p + 1];
+            v[SC_ATTEMPT] += 1;
+            v[SC_BLOCKED] += a.block_table[(c & 0xFFFFu) * (a.K + 1) + (c >> 16)];
+        }
+        if (a.ref) {
+            const uint32_t r = a.ref[i];
+            if (!(r & DEAD_BIT)) { const long long d = (long long)p - (long long)(r & POS_MASK); v[SC_DISP] += d; v[SC_DISP2] += d * d; v[SC_NDISP] += 1; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SC_COUNT; ++k) {
+        if (k == SC_MAXPOS) {
+            long long m = v[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+            if ((threadIdx.x & 63) == 0) atomicMax(&a.out[k], m);
+        } else {
+            const long long s = wave_sum(v[k]);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(&a.out[k]), (unsigned long long)s);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 std::string g_create_error;
 
@@ -1163,6 +1226,9 @@ struct aps_handle {
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     int graph_steps = 0;
+    uint32_t *d_ref = nullptr, *d_cnt_pm = nullptr;   // observables: reference state per slot [E][Npad], per-site counts [L]
+    uint8_t *d_block_table = nullptr; long long *d_scal = nullptr;
+    std::vector<char> ref_set;                         // per ensemble: reference marked (and slot order unchanged since)
     // per-kernel timing (aps_step_timed / aps_step_profile): an event before every launch, kind of that launch
     bool profiling = false;
     std::vector<int> prof_kind;
@@ -1698,7 +1764,7 @@ void aps_destroy(aps_handle *h) {
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    for (void *q : {(void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
                     h->d_nexit, h->d_tmp_sp8, h->d_tmp_tinfo};
@@ -1738,6 +1804,7 @@ int aps_set_state(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *si
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_set[(size_t)e] = n;
+    if (!h->ref_set.empty()) h->ref_set[(size_t)e] = 0;
     return APS_OK;
 }
 
@@ -1946,6 +2013,51 @@ int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launch
     return APS_OK;
 }
 
+int aps_mark_reference(aps_handle *h, int32_t e) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_mark_reference: bad ensemble");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_mark_reference: no state uploaded for this ensemble");
+    int rc;
+    if (!h->d_ref && (rc = dev_alloc(h, &h->d_ref, (size_t)h->E * h->Npad))) return rc;
+    if (h->ref_set.empty()) h->ref_set.assign((size_t)h->E, 0);
+    HIP_TRY(h, hipMemcpyAsync(h->d_ref + (size_t)e * h->Npad, h->d_src + (size_t)e * h->Npad, (size_t)h->Npad * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->ref_set[(size_t)e] = 1;
+    return APS_OK;
+}
+
+int aps_observe_scalars(aps_handle *h, int32_t e, int32_t x_wall, int32_t range_lo, int32_t range_hi, const uint8_t *block_table,
+                        int64_t *out11) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !out11) return fail(h, APS_ERR_ARG, "aps_observe_scalars: bad argument");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_observe_scalars: no state uploaded for this ensemble");
+    const int K = h->p.K, L = h->p.L;
+    int rc;
+    if (!h->d_scal && ((rc = dev_alloc(h, &h->d_scal, 16)) || (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L)) ||
+                       (rc = dev_alloc(h, &h->d_block_table, (size_t)(K + 1) * (K + 1))))) return rc;
+    std::vector<uint8_t> table((size_t)(K + 1) * (K + 1), 0);
+    if (block_table) table.assign(block_table, block_table + table.size());
+    else for (int cp = 0; cp <= K; ++cp) for (int cm = 0; cm <= K; ++cm) table[(size_t)cp * (K + 1) + cm] = cp + cm >= 1;
+    long long init[16] = {0};
+    init[SC_MAXPOS] = -1;
+    HIP_TRY(h, hipMemcpyAsync(h->d_block_table, table.data(), table.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_scal, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_cnt_pm, 0, (size_t)L * 4, h->stream));
+    const uint32_t *src = h->d_src + (size_t)e * h->Npad;
+    hipLaunchKernelGGL(count_sites, dim3((unsigned)(h->Npad / 256)), dim3(256), 0, h->stream, src, h->d_cnt_pm, (int)h->Npad);
+    ScalarArgs a{};
+    a.src = src; a.orig = h->d_orig + (size_t)e * h->Npad; a.block_table = h->d_block_table; a.cnt_pm = h->d_cnt_pm; a.out = h->d_scal;
+    a.ref = (h->d_ref && !h->ref_set.empty() && h->ref_set[(size_t)e]) ? h->d_ref + (size_t)e * h->Npad : nullptr;
+    a.Npad = (int)h->Npad; a.L = L; a.K = K; a.x_wall = x_wall; a.lo = range_lo; a.hi = range_hi;
+    hipLaunchKernelGGL(observe_scalars, dim3((unsigned)std::min<int64_t>(h->Npad / 256, 512)), dim3(256), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    long long res[16];
+    HIP_TRY(h, hipMemcpyAsync(res, h->d_scal, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < SC_COUNT; ++k) out11[k] = res[k];
+    return APS_OK;
+}
+
 int aps_method(aps_handle *h) { return h ? h->method : APS_ERR_ARG; }
 
 int aps_event_overhead(aps_handle *h, int32_t reps, double *ms_per_pair) {
@@ -2143,9 +2255,18 @@ int aps_resort(aps_handle *h) {
         std::vector<int32_t> pos((size_t)n); std::vector<int8_t> sg((size_t)n); std::vector<uint8_t> bd((size_t)n), al((size_t)n);
         int rc = aps_get_state(h, e, pos.data(), sg.data(), bd.data(), al.data(), n);
         if (rc) return rc;
+        std::vector<uint32_t> ref_orig((size_t)h->Npad);      // slot -> particle map before the re-sort
+        HIP_TRY(h, hipMemcpy(ref_orig.data(), h->d_orig + (size_t)e * h->Npad, ref_orig.size() * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> src, orig; long long gsum[2];
         pack_ensemble(h, pos.data(), sg.data(), bd.data(), al.data(), n, src, orig, gsum);
         if ((rc = upload_ensemble(h, e, src, orig))) return rc;
+        if (!h->ref_set.empty() && h->ref_set[(size_t)e]) {   // the reference follows the particles into the new slot order
+            std::vector<uint32_t> ref((size_t)h->Npad), oldorig((size_t)h->Npad), byorig((size_t)n, DEAD_BIT), neu((size_t)h->Npad, DEAD_BIT);
+            HIP_TRY(h, hipMemcpy(ref.data(), h->d_ref + (size_t)e * h->Npad, ref.size() * 4, hipMemcpyDeviceToHost));
+            for (int64_t sl = 0; sl < h->Npad; ++sl) if (ref_orig[(size_t)sl] != 0xFFFFFFFFu) byorig[ref_orig[(size_t)sl]] = ref[(size_t)sl];
+            for (int64_t sl = 0; sl < h->Npad; ++sl) if (orig[(size_t)sl] != 0xFFFFFFFFu) neu[(size_t)sl] = byorig[orig[(size_t)sl]];
+            HIP_TRY(h, hipMemcpy(h->d_ref + (size_t)e * h->Npad, neu.data(), neu.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     return APS_OK;
 }

@@ -6,14 +6,17 @@ from __future__ import annotations
 import numpy as np
 
 from . import observables
-from .particle_system import ParticleSystem, run_batched
+from .particle_system import ParticleSystem, run_batched, run_batched_statistics
 
 
 def sweep_over_betas(beta_values, n_runs_per_beta=10, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
-                     rng_seeds=None, keep_outputs=False):
+                     rng_seeds=None, keep_outputs=False, on_device=False):
     """Returns a dict with the keys the reference saves (`beta_values, means, stds, ses, D_means, D_ses, m_means,
     m_stds, m_ses, rho_means, rho_ses, block_means, block_ses`, ..._sweep_beta.py:952-968) plus `raw_by_beta`.
-    `rng_seeds[b][r]` seeds the initial condition of run r at beta b (None: unseeded, like the reference)."""
+    `rng_seeds[b][r]` seeds the initial condition of run r at beta b (None: unseeded, like the reference).
+    `on_device=True` evaluates the observables from integer sums taken on the GPU at each observation time
+    (run_batched_statistics; needs k_exit = 0) instead of from the M x L arrays of `run()`; `run_kwargs` may then
+    only hold T and obs_dt."""
     ps_kwargs, init_kwargs, run_kwargs = dict(ps_kwargs or {}), dict(init_kwargs or {}), dict(run_kwargs or {})
     systems, owner = [], []
     for bi, beta in enumerate(beta_values):
@@ -21,8 +24,14 @@ def sweep_over_betas(beta_values, n_runs_per_beta=10, ps_kwargs=None, init_kwarg
             rng = None if rng_seeds is None else np.random.default_rng(int(rng_seeds[bi][r]))
             systems.append(ParticleSystem(beta=beta, rng=rng, **ps_kwargs, **init_kwargs))
             owner.append(bi)
-    outs = run_batched(systems, **run_kwargs)
-    rows = [observables.run_observables(out, ps.L, ps.dx) for ps, out in zip(systems, outs)]
+    if on_device:
+        if keep_outputs:
+            raise ValueError("on_device=True keeps no per-run outputs")
+        outs = None
+        rows = run_batched_statistics(systems, **{k: v for k, v in run_kwargs.items() if k in ("T", "obs_dt")})
+    else:
+        outs = run_batched(systems, **run_kwargs)
+        rows = [observables.run_observables(out, ps.L, ps.dx) for ps, out in zip(systems, outs)]
     res = {k: [] for k in ("means", "stds", "ses", "D_means", "D_ses", "m_means", "m_stds", "m_ses", "rho_means", "rho_ses",
                            "block_means", "block_ses", "raw_by_beta")}
     for bi in range(len(beta_values)):

@@ -111,3 +111,76 @@ def ensemble_statistics(rows):
                 m_mean=float(col["m"].mean()), m_std=sd["m"], m_se=sd["m"] / root,
                 rho_mean=float(col["rho"].mean()), rho_se=sd["rho"] / root,
                 block_mean=float(col["block"].mean()), block_se=sd["block"] / root)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same five observables from the device-side integer sums (aps_observe_scalars): no M x L arrays leave the GPU.
+class DeviceObservables:
+    """Per-run accumulator.  `plan(k)` tells the stepping loop what to ask the device for at observation k,
+    `add(k, sums, front)` stores the answer, `result()` evaluates the reference's formulas
+    (PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py:123-229, :316-319, :500-525) on the stored sums.
+    Exact for the integer parts; the float parts differ from the array formulas only by summation order."""
+
+    def __init__(self, times, L, dx, K, boundary_xmin=0.99, max_boundary_fraction=0.06, min_window_fraction=0.10,
+                 front_window_fraction=0.05):
+        self.times, self.L, self.dx, self.K = np.asarray(times, dtype=float), int(L), float(dx), int(K)
+        self.M = len(self.times)
+        self.grid = np.linspace(0.0, 1.0, self.L)
+        self.gdx = self.grid[1] - self.grid[0]
+        self.x_wall = int(np.searchsorted(self.grid, boundary_xmin, side="left"))
+        self.max_boundary_fraction, self.min_window_fraction = max_boundary_fraction, min_window_fraction
+        self.wf = front_window_fraction
+        self.start = int(0.65 * self.M)
+        self.rows = [None] * self.M
+        self.front = [None] * self.M
+
+    def block_table(self, n_live):
+        """Is a right neighbour with (plus, minus) particles 'blocking'?  total density >= 1 in the reference's units
+        rho = count / (N_now * dx), evaluated with the reference's float operations."""
+        denom = float(max(1, n_live)) * self.dx
+        cp, cm = np.meshgrid(np.arange(self.K + 1), np.arange(self.K + 1), indexing="ij")
+        return ((cp / denom).astype(float) + (cm / denom).astype(float) >= 1.0).astype(np.uint8)
+
+    def front_range(self, max_pos):
+        """Site range [lo, hi] of the reference's front window below the right-most occupied site."""
+        x_front = self.grid[max_pos]
+        lo = int(np.searchsorted(self.grid, x_front - self.wf, side="left"))
+        return lo, int(max_pos)
+
+    def add(self, k, sums, n_front=None):
+        self.rows[k] = dict(sums)
+        self.front[k] = n_front
+
+    def result(self):
+        M, dx, gdx = self.M, self.dx, self.gdx
+        n = np.array([r["n"] for r in self.rows], dtype=float)
+        dens = 1.0 / (np.maximum(n, 1.0) * dx)                     # one particle in the reference's density units
+        mass = n * dens * gdx
+        frac_boundary = np.array([r["n_wall"] for r in self.rows]) * dens * gdx / (mass + 1e-12)
+        flagged = np.flatnonzero(frac_boundary >= self.max_boundary_fraction)
+        start = self.start
+        if flagged.size == 0:
+            end = M
+        else:
+            end = M if flagged[start:].size == 0 else start
+            shortest = max(3, int(self.min_window_fraction * M))
+            if end - start < shortest:
+                end = min(M, start + shortest)
+        com = (np.array([r["sum_pos"] for r in self.rows]) / (self.L - 1.0)) * dens / (n * dens + 1e-12)
+        v_ts = np.gradient(com, self.times)
+        m_glob = np.array([r["sum_sigma"] / r["n"] if r["n"] else np.nan for r in self.rows])
+        fronts = [self.front[k] * dens[k] * gdx / self.wf for k in range(start, end) if self.front[k] is not None]
+        att = sum(self.rows[k]["attempts"] * dens[k] for k in range(start, end))
+        blk = sum(self.rows[k]["blocked"] * dens[k] for k in range(start, end))
+        spread, lag = [], []
+        for k in range(start + 1, end):
+            r = self.rows[k]
+            nd = r["n_d"]
+            if nd < 2:
+                continue
+            spread.append(dx * dx * (r["sum_d2"] - r["sum_d"] ** 2 / nd) / (nd - 1))
+            lag.append(self.times[k] - self.times[start])
+        D = np.polyfit(lag, spread, 1)[0] if len(lag) >= 2 else float("nan")
+        return dict(v=float(np.mean(v_ts[start:end])), D=float(D), m=float(np.mean(m_glob[start:end])),
+                    rho=float(np.mean(fronts)) if fronts else float("nan"), block=float(blk / att) if att else 0.0,
+                    window=(start, end), v_ts=v_ts, frac_boundary=frac_boundary, m_global=m_glob)

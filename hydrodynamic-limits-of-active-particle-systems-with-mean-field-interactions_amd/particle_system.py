@@ -390,3 +390,54 @@ def run_batched(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var=False
         "rho_hat_complex": rec["hat"], "fft_amp_list": rec["amp"], "var_list": rec["var"],
         "exit_times": [float(t) for t in ex[:, 0]], "exit_positions": [int(x) for x in ex[:, 1]],
     } for rec, ex in zip(recs, exits)]
+
+
+def run_batched_statistics(systems, T=10.0, obs_dt=0.01):
+    """The sweep drivers' per-run observables (v_eff, D_eff, mean magnetisation, front density, blocking
+    probability; ..._sweep_beta.py:85-95) for several systems stepped together, WITHOUT materialising the M x L
+    arrays of `run()`: at every observation time the device returns a dozen integer sums per ensemble
+    (aps_observe_scalars).  Only valid while no particle exits (k_exit = 0, as in every reference sweep); returns a
+    list of dicts like observables.run_observables."""
+    from . import observables
+    first = systems[0]
+    for ps in systems[1:]:
+        for k in _SHAPE_ATTRS:
+            if getattr(ps, k) != getattr(first, k):
+                raise ValueError(f"run_batched_statistics: systems differ in {k}")
+    if first.k_exit:
+        raise ValueError("run_batched_statistics needs k_exit = 0 (use run_batched and observables.run_observables)")
+    inits = [ps.init_particles() for ps in systems]
+    seed = first.seed if first.seed is not None else int(first.rng.random() * 2.0 ** 53)
+    if first.dt is None:
+        first.dt = min(ps.default_dt() for ps in systems)
+    for ps in systems:
+        ps.dt, ps.seed_used = first.dt, seed
+    dt = first.dt
+    cap = max(1, max(len(p) for p, _ in inits))
+    h = first._make_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
+    times_obs = np.arange(0.0, T, obs_dt)
+    accs = [observables.DeviceObservables(times_obs, first.L, first.dx, first.K) for _ in systems]
+    try:
+        for e, (pos0, sigma0) in enumerate(inits):
+            h.set_state(pos0, sigma0, ensemble=e)
+        done = 0
+        for k, t_obs in enumerate(times_obs):
+            want = int(math.ceil(t_obs / dt - 1e-9))
+            if want > done:
+                h.step(want - done)
+                done = want
+            for e, acc in enumerate(accs):
+                if k == acc.start:
+                    h.mark_reference(ensemble=e)
+                n_live = len(inits[e][0])                            # no exits: the particle number is constant
+                sums = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, block_table=acc.block_table(n_live))
+                n_front = None
+                if k >= acc.start and sums["max_pos"] >= 0:
+                    lo, hi = acc.front_range(sums["max_pos"])
+                    n_front = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, range_lo=lo, range_hi=hi)["n_range"]
+                acc.add(k, sums, n_front)
+        for ps in systems:
+            ps.steps_done = done
+    finally:
+        h.close()
+    return [acc.result() for acc in accs]

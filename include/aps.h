@@ -124,6 +124,18 @@ int aps_comm_init(aps_handle *h, const uint8_t *id128);
 /* replaces the observation block (ref :517-536): site histograms and the m-field on all L sites. */
 int aps_observe(aps_handle *h, int32_t ensemble, int64_t *counts_p, int64_t *counts_m, double *m_field);
 
+/* Driver-side observables on the device (the sums behind compute_v_eff_and_window, compute_rho_eff,
+ * compute_blocking_probability, compute_mean_magnetizatoin, compute_D_eff_active of
+ * PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py:123-229, :316-319, :500-525), all exact integers over the live
+ * particles of one ensemble: out11 = { n, sum sigma, sum pos, #(pos >= x_wall), max pos (-1 if none),
+ * #(range_lo <= pos <= range_hi), #(plus particles on sites < L-1), of those: blocked by the right neighbour,
+ * sum d, sum d^2, #d } with d = pos - reference pos of the same particle (aps_mark_reference; zeros if none marked).
+ * block_table[(K+1)*(K+1)], indexed [plus count * (K+1) + minus count] of the right neighbour site, says whether
+ * that occupancy blocks (NULL: any particle blocks). */
+int aps_mark_reference(aps_handle *h, int32_t ensemble);
+int aps_observe_scalars(aps_handle *h, int32_t ensemble, int32_t x_wall, int32_t range_lo, int32_t range_hi,
+                        const uint8_t *block_table, int64_t *out11);
+
 /* m-field for a caller-supplied histogram: compute_local_m_field(counts_p, counts_m) (ref :216-246) */
 int aps_field_from_counts(aps_handle *h, int32_t ensemble, const int64_t *counts_p, const int64_t *counts_m,
                           double *m_field);
