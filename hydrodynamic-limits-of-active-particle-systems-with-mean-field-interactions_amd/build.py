@@ -11,17 +11,19 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "aps_hip.hip")
+SRCS = [SRC, os.path.join(HERE, "csrc", "pde_hip.hip")]        # particle stepper; hydrodynamic-limit PDE solver
 HDR = os.path.join(ROOT, "include", "aps.h")
+HDRS = [HDR, os.path.join(ROOT, "include", "pde.h")]
 LIB = os.path.join(HERE, "libaps_hip.so")
 ARCH = "gfx950"
 
 
 def build(force=False, save_temps=False, verbose=False):
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+    newest = max(os.path.getmtime(f) for f in SRCS + HDRS)
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
     cmd = ["hipcc", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB, SRC]
+           "-I", os.path.join(ROOT, "include"), "-o", LIB] + SRCS
     if save_temps:
         tmp = os.path.join(HERE, "csrc", "_temps")
         os.makedirs(tmp, exist_ok=True)

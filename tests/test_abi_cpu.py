@@ -67,3 +67,40 @@ def test_init_particles_matches_reference_fixture(golden):
         ps = ParticleSystem(rng=np.random.default_rng(c["seed"]), **kw)
         pos, sigma = ps.init_particles()
         assert np.array_equal(pos, g[f"c{idx}_pos"]) and np.array_equal(sigma, g[f"c{idx}_sigma"]), c["tag"]
+
+
+def test_pde_header_symbols_exported_and_struct_layout():
+    """include/pde.h: every declared function is exported by the library; PdeParams mirrors struct pde_params."""
+    import ctypes as C
+    import re
+    capi = importlib.import_module(PKG + ".capi")
+    pde = importlib.import_module(PKG + ".pde")
+    lib = capi.load()
+    with open(os.path.join(os.path.dirname(capi.HEADER_PATH), "pde.h")) as fh:
+        text = fh.read()
+    names = sorted(set(re.findall(r"\b(pde_[a-z_0-9]+)\s*\(", text)))
+    assert names == ["pde_last_error", "pde_solve_batch"]
+    for n in names:
+        assert hasattr(lib, n), n
+    body = re.search(r"typedef struct pde_params \{(.*?)\} pde_params;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, rest = decl.split(None, 1)
+        fields += [re.sub(r"\[.*\]", "", f.strip()) for f in rest.split(",")]
+    assert fields == [f[0] for f in pde.PdeParams._fields_]
+    assert C.sizeof(pde.PdeParams) == 12 * 4 + 5 * 8 + 8
+
+
+def test_pde_drop_in_module_fails_loudly_without_gpu():
+    from IMEX_PDE_solver_class import IMEXPDE
+    capi = importlib.import_module(PKG + ".capi")
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    s = IMEXPDE(L=64, T=0.01, seed=1)
+    s.initialize(n_tracers=4)
+    with pytest.raises(capi.ApsError):
+        s.solve()
