@@ -132,15 +132,51 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def bench_pde(args):
+    """--workload pde (for the record, never the default line): the reference's sweep shape
+    (IMEX_PDE_solver_run_sweep.py:26-48: L=1000, dt=5e-4, periodic, bidirectional, flat kernel, 1000 tracers) for
+    256 beta values in one launch; a step = one pass of IMEXPDE.solve's loop body for one system."""
+    pde = importlib.import_module(PKG + ".pde")
+    kw = dict(L=1000, xlim=1.0, dt=5e-4, gamma=0.2, lam=0.6, bc="periodic", active_model="bidirectional",
+              gaussian_kernel=True, kernel_sigma=1e5 - 10, snapshot_interval=50, seed=0)
+    nsteps, nsys = args.steps, 256
+    s = pde.IMEXPDE(T=nsteps * kw["dt"], beta=2.0, record_fft=False, **kw)
+    s.initialize(mode="homogeneous", rho0=1.0, noise=0.3, n_tracers=1000)
+    betas = np.linspace(0.0, 3.0, nsys)
+    s.solve_batch(betas[:2])                                   # warm-up (module load, first launch)
+    r = s.solve_batch(betas)
+    ms = r["kernel_ms"]
+    out = {"metric": "PDE system-steps/sec (IMEXPDE.solve loop body), 256 systems x L=1000", "value": nsys * (nsteps + 1) / (ms * 1e-3),
+           "unit": "system-steps/s", "n_gpus": 1, "steps": nsteps, "warmup": 0, "ms_per_step": ms / (nsteps + 1),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "IMEX_PDE_solver_run_sweep.py shape: L=1000, dt=5e-4, periodic, bidirectional, ring-wide "
+                                  "Gaussian kernel (1001 taps), 1000 tracers, 256 beta values in one launch",
+                      "per_system_steps_per_s": (nsteps + 1) / (ms * 1e-3)}}
+    if not args.no_cpu_baseline:
+        from oracle.pde_numpy import PdeOracle
+        n_cpu = 300
+        orc = PdeOracle(T=n_cpu * kw["dt"], beta=2.0, **kw)
+        orc.initialize(mode="homogeneous", rho0=1.0, noise=0.3, n_tracers=1000)
+        t0 = time.perf_counter()
+        orc.solve()
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": (n_cpu + 1) / el, "unit": "system-steps/s", "cores": 1, "kind": "port",
+                               "sample": f"{n_cpu + 1} steps of ONE system by oracle/pde_numpy.py (scipy spsolve + numpy rfft, "
+                                         f"bit-identical to the reference's IMEXPDE), {el:.1f} s"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2"] + sorted(EXTRA))
+    ap.add_argument("--workload", default="config2", choices=["config2", "pde"] + sorted(EXTRA))
     ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs"])
     args = ap.parse_args()
+    if args.workload == "pde":
+        return bench_pde(args)
     w = dict(WORK) if args.workload == "config2" else dict(EXTRA[args.workload])
     n_ens = len(w.get("betas", [0]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
