@@ -166,17 +166,54 @@ def bench_pde(args):
     print(json.dumps(out))
 
 
+def bench_gillespie(args):
+    """--workload gillespie (for the record): the reference's sweep shape (..._sweep_beta.py:829-857: L=1000, N=500, K=1,
+    sigma=0.005, T=20, obs_dt=0.1) as 1024 independent systems (beta = linspace(0,3,32) x 32 runs) in ONE launch of the
+    device-resident exact event loop; unit = Gillespie events."""
+    gil = importlib.import_module(PKG + ".gillespie")
+    L, N, nsys = 1000, 500, 1024
+    rng = np.random.default_rng(0)
+    states = []
+    for _ in range(nsys):
+        states.append((rng.choice(L, size=N, replace=False).astype(np.int32), rng.choice(np.array([1, -1], np.int8), size=N)))
+    betas = np.repeat(np.linspace(0.0, 3.0, 32), 32)
+    times = np.arange(0.0, 20.0, 0.1)
+    kw = dict(L=L, K=1, periodic=False, sigma_grid=0.005 * L, rate_diffusion=0.02, rate_active=5.0, times_obs=times, T=20.0, seed=1)
+    gil.run_raw(betas=betas[:4], states=states[:4], want_states=False, **kw)          # warm-up
+    r = gil.run_raw(betas=betas, states=states, want_states=False, **kw)
+    ev, ms = int(r["n_events"].sum()), r["kernel_ms"]
+    out = {"metric": "exact Gillespie events/sec, 1024 systems x N=500 (reference sweep shape)", "value": ev / (ms * 1e-3), "unit": "events/s",
+           "n_gpus": 1, "steps": ev, "warmup": 0, "ms_per_step": ms / max(1, int(r["n_events"].max())), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "L=1000, N=500, K=1, sigma=0.005, rate_active=5, rate_diffusion=0.02, T=20, obs_dt=0.1; 32 beta x 32 runs "
+                                  "as 1024 persistent workgroups", "events_per_system": float(r["n_events"].mean()),
+                      "per_system_events_per_s": float(r["n_events"].max()) / (ms * 1e-3), "kernel_ms": ms}}
+    if not args.no_cpu_baseline:
+        from oracle.gillespie_numpy import GillespieOracle
+        orc = GillespieOracle(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7, N=N, scale_rates=False,
+                              local_kernel_sigma=0.005, site_capacity=1, rng=np.random.default_rng(0))
+        t0 = time.perf_counter()
+        orc.run(T=20.0, obs_dt=0.1, max_events=20000)
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": orc.n_events / el, "unit": "events/s", "cores": 1, "kind": "port",
+                               "sample": f"{orc.n_events} events of ONE system by oracle/gillespie_numpy.py (the reference's loop, "
+                                         f"bit-identical for seeded generators), {el:.1f} s"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2", "pde"] + sorted(EXTRA))
+    ap.add_argument("--workload", default="config2", choices=["config2", "pde", "gillespie"] + sorted(EXTRA))
     ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs"])
     args = ap.parse_args()
     if args.workload == "pde":
         return bench_pde(args)
+    if args.workload == "gillespie":
+        return bench_gillespie(args)
     w = dict(WORK) if args.workload == "config2" else dict(EXTRA[args.workload])
     n_ens = len(w.get("betas", [0]))
     world = int(os.environ.get("WORLD_SIZE", "1"))

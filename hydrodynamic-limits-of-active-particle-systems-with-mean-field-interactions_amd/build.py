@@ -11,9 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "aps_hip.hip")
-SRCS = [SRC, os.path.join(HERE, "csrc", "pde_hip.hip")]        # particle stepper; hydrodynamic-limit PDE solver
+SRCS = [SRC, os.path.join(HERE, "csrc", "pde_hip.hip"), os.path.join(HERE, "csrc", "gillespie_hip.hip")]   # stepper; PDE solver; exact event loop
 HDR = os.path.join(ROOT, "include", "aps.h")
-HDRS = [HDR, os.path.join(ROOT, "include", "pde.h")]
+HDRS = [HDR, os.path.join(ROOT, "include", "pde.h"), os.path.join(HERE, "csrc", "aps_common.hpp"), os.path.join(ROOT, "include", "gillespie.h")]
 LIB = os.path.join(HERE, "libaps_hip.so")
 ARCH = "gfx950"
 

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "aps.h"
+#include "aps_common.hpp"
 
 namespace {
 
@@ -60,57 +61,6 @@ constexpr int PLAN_CAP = 192;                 // planned source tiles per target
 
 enum { EV_NONE = 0, EV_LEFT = 1, EV_RIGHT = 2, EV_FWD = 3, EV_BIND = 4, EV_UNBIND = 5, EV_EXIT = 6, EV_FLIP = 7 };
 enum { V_FAST = 0, V_GENERIC = 1, V_MIRROR = 2 };
-
-// ---------------------------------------------------------------------------------------------
-// deterministic exp: mul, fma, rint and an exponent insert only -> identical bits on host and device
-__host__ __device__ inline double aps_exp(double x) {
-    const double LOG2E = 0x1.71547652b82fep+0, LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33;
-    x = x > 700.0 ? 700.0 : (x < -700.0 ? -700.0 : x);
-    const double kf = rint(x * LOG2E);
-    double r = fma(-kf, LN2_HI, x);
-    r = fma(-kf, LN2_LO, r);
-    double p = 0x1.6124613a86d09p-33;                       // 1/13!
-    p = fma(p, r, 0x1.1eed8eff8d898p-29);
-    p = fma(p, r, 0x1.ae64567f544e4p-26);
-    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = fma(p, r, 0x1.71de3a556c734p-19);
-    p = fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = fma(p, r, 0x1.1111111111111p-7);
-    p = fma(p, r, 0x1.5555555555555p-5);
-    p = fma(p, r, 0x1.5555555555555p-3);
-    p = fma(p, r, 0x1.0000000000000p-1);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const long long k = (long long)kf, k1 = k / 2, k2 = k - k1;
-    union { unsigned long long u; double d; } s1, s2;
-    s1.u = (unsigned long long)(k1 + 1023) << 52;
-    s2.u = (unsigned long long)(k2 + 1023) << 52;
-    return p * s1.d * s2.d;
-}
-
-// Philox4x32-10 (Salmon et al., Random123): counter-based, so a particle's draw depends only on
-// (seed, step, particle index, ensemble) -- never on which thread, GPU or tiling evaluated it.
-__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                     uint32_t out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-struct Model {               // by-value kernel argument: everything the rate code needs
-    int L, K, periodic, field_mode, minus_anchor, immobilize, suppress_flip, crowding;
-    double rate_diffusion, rate_active, k_on, k_off, k_exit, dt;
-    uint32_t seed_lo, seed_hi;
-    int ens_base;
-};
 
 struct PairArgs {
     Model m;
@@ -387,47 +337,6 @@ __device__ __forceinline__ void stage_table(double *lds, const double *__restric
 // LDS holds only the weight table (tlen + 1 doubles) when it fits
 __host__ __device__ inline size_t lds_table_bytes(int tlen, bool tab_lds) { return tab_lds ? ((size_t)tlen + 2) / 2 * 2 * sizeof(double) : 0; }
 __host__ __device__ inline size_t lds_total_bytes(int tlen, bool tab_lds) { return lds_table_bytes(tlen, tab_lds) + (size_t)WAVES * TILE * sizeof(uint32_t); }
-
-struct Channels { double diff, act, flip, bind, unbind, leave, left, right, total; };
-
-// Rate table of one particle: the arithmetic of step_gillespie's vector section (ref :261-351),
-// operation for operation (same association order as the NumPy expressions).
-__device__ inline Channels channels(const Model &M, bool anchored_site, int p, int spin, bool bound, double mloc,
-                                    double beta, int occ_self, int occ_left, int occ_right) {
-    const int L = M.L, K = M.K;
-    const bool plus = spin > 0;
-    double flip = aps_exp(-beta * (double)spin * mloc);
-    if (M.suppress_flip && bound) flip = 0.0;
-    // target sites: forward = right neighbour for +, own site for -; walls clip, torus wraps
-    const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == L - 1;
-    const int o_l = wall_l ? occ_self : occ_left, o_r = wall_r ? occ_self : occ_right;
-    const int o_f = plus ? o_r : occ_self;
-    const bool open_l = !wall_l && o_l < K, open_r = !wall_r && o_r < K, open_f = plus && open_r;
-    double hl = M.rate_diffusion * (double)open_l, hr = M.rate_diffusion * (double)open_r;
-    double act = (plus || !M.minus_anchor) ? M.rate_active : 0.0;
-    double leave = 0.0;
-    const bool held = M.immobilize && !plus && anchored_site && bound;
-    if (held) { act = 0.0; hl = 0.0; hr = 0.0; leave = M.k_exit; }
-    double diff = hl + hr;
-    if (!(plus && open_f)) act = 0.0;
-    if (M.crowding) {
-        double ff = 1.0 - (double)o_f / (double)K, fl = 1.0 - (double)o_l / (double)K, fr = 1.0 - (double)o_r / (double)K;
-        ff = ff < 0.0 ? 0.0 : (ff > 1.0 ? 1.0 : ff);
-        fl = fl < 0.0 ? 0.0 : (fl > 1.0 ? 1.0 : fl);
-        fr = fr < 0.0 ? 0.0 : (fr > 1.0 ? 1.0 : fr);
-        act *= ff;
-        hl = M.rate_diffusion * (double)open_l * fl;
-        hr = M.rate_diffusion * (double)open_r * fr;
-        diff = hl + hr;
-    }
-    if (held) { diff = 0.0; act = 0.0; }
-    Channels c;
-    c.bind = (!bound && !plus && anchored_site && occ_self < K) ? M.k_on : 0.0;
-    c.unbind = bound ? M.k_off : 0.0;
-    c.diff = diff; c.act = act; c.flip = flip; c.leave = leave; c.left = hl; c.right = hr;
-    c.total = ((((diff + act) + flip) + c.bind) + c.unbind) + leave;
-    return c;
-}
 
 // Epilogue shared by both formulations: m = clip(S/W) -> rates (ref :261-351) -> Philox draw -> proposal byte
 // (event code | (free capacity of the hop target - 1) << 3).  c0/cl/cr = occupancy of the own / left / right site.
@@ -1277,54 +1186,7 @@ struct Rccl {
     }
 } g_rccl;
 
-// Weight table (DESIGN.md "Weight table"): unnormalised taps of gaussian_filter1d(truncate=4) with the
-// reflected images folded in, rounded to the grid 2^-q that keeps every possible partial sum exact.
-void build_table(aps_handle *h) {
-    const aps_params &p = h->p;
-    h->table.clear();
-    h->q = 0;
-    if (!(p.sigma_grid > 0.0)) { h->tlen = 0; h->table.push_back(0.0); return; }
-    const double s2 = p.sigma_grid * p.sigma_grid;
-    const int64_t L = p.L;
-    const int64_t lw = p.periodic ? L / 2 : (int64_t)(4.0 * p.sigma_grid + 0.5);
-    const int64_t tmax = p.periodic ? L / 2 : std::min(lw, L);
-    std::vector<double> w((size_t)tmax + 1);
-    double wmax = 0.0;
-    for (int64_t t = 0; t <= tmax; ++t) {
-        double acc = 0.0;
-        if (p.periodic) {
-            const double a = (double)t;
-            acc = aps_exp(-(0.5 * a * a) / s2);
-        } else {
-            for (int64_t k = 0;; ++k) {
-                const int64_t d1 = t + 2 * L * k, d2 = 2 * L * k - t;
-                bool any = false;
-                if (d1 <= lw) { const double a = (double)d1; acc += aps_exp(-(0.5 * a * a) / s2); any = true; }
-                if (k > 0 && d2 <= lw) { const double a = (double)d2; acc += aps_exp(-(0.5 * a * a) / s2); any = true; }
-                if (!any) break;
-            }
-        }
-        w[(size_t)t] = acc;
-        wmax = std::max(wmax, acc);
-    }
-    const double nterm = p.periodic ? (double)p.K * (2.0 * (double)tmax + 1.0)
-                                    : (lw < L ? (double)p.K * (2.0 * (double)lw + 1.0) : 2.0 * (double)p.K * (double)L);
-    const double bound = std::ceil(nterm * wmax);
-    int bits = 0;
-    while (std::ldexp(1.0, bits) <= bound) ++bits;
-    int q = std::min(45, 51 - bits);
-    const double up = std::ldexp(1.0, q), down = std::ldexp(1.0, -q);
-    int n = 0;
-    for (int64_t t = 0; t <= tmax; ++t) {
-        w[(size_t)t] = std::rint(w[(size_t)t] * up) * down;
-        if (w[(size_t)t] != 0.0) n = (int)t + 1;
-    }
-    w.resize((size_t)n);
-    w.push_back(0.0);
-    h->table = std::move(w);
-    h->tlen = n;
-    h->q = q;
-}
+void build_table(aps_handle *h) { weight_table(h->p.sigma_grid, h->p.L, h->p.K, h->p.periodic != 0, h->table, h->tlen, h->q); }
 
 template <typename T>
 int dev_alloc(aps_handle *h, T **ptr, size_t count) {

@@ -84,8 +84,9 @@ class ParticleSystem:
         self.device = int(device)
         self.sort_by_site = bool(sort_by_site)
         self.ensemble = int(ensemble)          # Philox counter word 3 (independent streams under one seed)
-        if mode not in ("sync", "gillespie"):
-            raise ValueError("mode must be 'sync' (fixed-dt stepper) or 'gillespie' (one exact event per iteration)")
+        if mode not in ("sync", "gillespie", "gillespie_gpu"):
+            raise ValueError("mode must be 'sync' (fixed-dt stepper), 'gillespie' (one exact event per iteration, drawn "
+                             "from rng on the host) or 'gillespie_gpu' (the exact event loop resident on the GPU)")
         self.mode = mode
         if method not in capi.METHODS:
             raise ValueError("method must be 'auto', 'pairs' (all-pairs kernel) or 'lattice' (incremental lattice field)")
@@ -228,6 +229,9 @@ class ParticleSystem:
     def run(self, T=10.0, obs_dt=0.01, record_fft=False, record_var=False):
         if self.mode == "gillespie":
             return self._run_gillespie(T, obs_dt, record_fft, record_var)
+        if self.mode == "gillespie_gpu":
+            from .gillespie import run_batched_exact
+            return run_batched_exact([self], T=T, obs_dt=obs_dt, record_fft=record_fft, record_var=record_var)[0]
         return run_batched([self], T=T, obs_dt=obs_dt, record_fft=record_fft, record_var=record_var)[0]
 
     def _run_gillespie(self, T, obs_dt, record_fft, record_var):

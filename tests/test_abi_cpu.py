@@ -104,3 +104,28 @@ def test_pde_drop_in_module_fails_loudly_without_gpu():
     s.initialize(n_tracers=4)
     with pytest.raises(capi.ApsError):
         s.solve()
+
+
+def test_gillespie_header_symbols_exported_and_struct_layout():
+    """include/gillespie.h: every declared function is exported; GilParams mirrors struct gil_params."""
+    import ctypes as C
+    import re
+    capi = importlib.import_module(PKG + ".capi")
+    gil = importlib.import_module(PKG + ".gillespie")
+    lib = capi.load()
+    with open(os.path.join(os.path.dirname(capi.HEADER_PATH), "gillespie.h")) as fh:
+        text = fh.read()
+    names = sorted(set(re.findall(r"\b(gil_[a-z_0-9]+)\s*\(", text)))
+    assert names == ["gil_last_error", "gil_run_batch"]
+    for n in names:
+        assert hasattr(lib, n), n
+    body = re.search(r"typedef struct gil_params \{(.*?)\} gil_params;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            rest = decl.rsplit(None, 1)[1] if "," not in decl else decl.split(None, 1)[1]
+            fields += [f.strip().lstrip("*") for f in rest.split(",")]
+    assert fields == [f[0] for f in gil.GilParams._fields_]
+    assert C.sizeof(gil.GilParams) == 14 * 4 + 7 * 8 + 8 + 8 + 5 * 8
