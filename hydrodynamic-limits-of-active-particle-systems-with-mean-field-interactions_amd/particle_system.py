@@ -381,7 +381,8 @@ def run_batched(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var=False
                     rec["hat"][k], rec["amp"][k] = spec, np.abs(spec)
                     if record_var:                      # kept only together with the FFT (ref :499-507)
                         rec["var"][k] = float(np.var(u))
-            h.resort()
+            if h.method == "pairs":                     # tile culling of the all-pairs kernel likes site-sorted slots;
+                h.resort()                              # the lattice formulation does not care about the slot order
         exits = [h.exits(ensemble=e) for e in range(E)]
         for ps in systems:
             ps.steps_done = done_steps
