@@ -44,18 +44,12 @@ constexpr uint32_t SPIN_BIT = 1u << 27;
 constexpr uint32_t BOUND_BIT = 1u << 28;
 constexpr uint32_t DEAD_BIT = 1u << 29;
 constexpr uint32_t DEAD_P8 = POS_MASK << 3;   // far-away site (x8) every distance test rejects
-constexpr uint32_t SG_PLUS = 0x3FF00000u;     // high words of +1.0 / -1.0
-constexpr uint32_t SG_MINUS = 0xBFF00000u;
 constexpr int TILE = 64;                      // slots per tile = one wavefront of targets
 #ifndef APS_WAVES
 #define APS_WAVES 4
 #endif
 constexpr int WAVES = APS_WAVES;              // waves per workgroup; they split the source tiles of one target tile
 constexpr int NTHREADS = TILE * WAVES;
-#ifndef APS_LIST_CAP
-#define APS_LIST_CAP 256
-#endif
-constexpr int LIST_CAP = APS_LIST_CAP;        // in-kernel work list entries per scan round (overflow fallback only)
 constexpr int MAX_SPLIT = 16;                 // shares a target tile's source list can be cut into
 constexpr int PLAN_CAP = 192;                 // planned source tiles per target tile (more -> in-kernel scan)
 

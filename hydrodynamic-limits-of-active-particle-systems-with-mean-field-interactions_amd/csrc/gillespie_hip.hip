@@ -45,15 +45,6 @@ struct GilArgs {
     int32_t *n_recorded; long long *n_events; double *t_final, *exits; int32_t *n_exits;
 };
 
-__device__ inline double wg_sum(double v, double *red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 __device__ inline long long wg_sum_ll(long long v, long long *red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
