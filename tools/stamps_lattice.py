@@ -5,16 +5,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
+workload = "config2"
 extra = sys.argv[1:]
+if extra and not extra[0].startswith("-"):
+    workload, extra = extra[0], extra[1:]
 lib = f"/tmp/libaps_stamps_lat_{'_'.join(x.strip('-D') for x in extra)}.so"
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DAPS_STAMPS",
                 *extra, "-I", os.path.join(ROOT, "include"), "-o", lib, os.path.join(ROOT, PKG, "csrc", "aps_hip.hip")], check=True)
 capi = importlib.import_module(PKG + ".capi")
 capi.LIB_PATH = lib
 import bench
-w = dict(bench.WORK)
+w = dict(bench.WORK) if workload == "config2" else dict(bench.EXTRA[workload])
 h = bench.make_handle(capi, w, method="lattice")
-h.set_state(*bench.initial_state(w))
+for e in range(len(w.get("betas", [0]))):
+    h.set_state(*bench.initial_state(w), ensemble=e)
 h.step(200)
 prof = h.step_profile(20)
 print({k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]}, "us per launch (event-bracketed)")
