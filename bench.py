@@ -31,6 +31,9 @@ WORK = dict(N=100_000, L=200_000, K=1, xlim=1.0, sigma=0.005, beta=0.7, rate_act
 EXTRA = {
     "config4": dict(WORK, N=50_000, L=100_000, betas=[3.0 * i / 15 for i in range(16)]),     # 16 beta ensembles, one GPU
     "config5": dict(WORK, N=1_000_000, L=2_000_000),                                          # f64 here (no f32 path)
+    # not a BASELINE configuration: the same model at a size where the working set (1.5 GB) no longer fits the caches,
+    # short-ranged kernel (sigma_g = 10 sites) -- shows the kernels against the HBM roofline they are priced on
+    "hbm": dict(WORK, N=16_000_000, L=32_000_000, sigma=10.0 / 32_000_000),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # SURVEY 8d (all-pairs): 4 B state read + 4 B write + 4 B proposal + 4 B occupancy/commit
@@ -341,7 +344,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
                                 "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on") if args.workload == "config2"
-                               else f"BASELINE {args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma=0.005, dt=0.0125",
+                               else f"{'BASELINE ' if args.workload.startswith('config') else ''}{args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma_g={w['sigma'] * w['L']:.0f} sites, dt=0.0125",
                    "method": h_method,
                    "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"
                                + (f" ({comm_path})" if sharded_path else "")},
