@@ -1423,10 +1423,12 @@ int ensure_lattice(aps_handle *h) {
                 if (rc) return rc;
             }
         h->field_dirty = false;
+        // the step words are kept by the kernels themselves (step n writes n + 1 into the other word); set them once more
+        // here so that a handle whose state was replaced mid-run starts from a known pair
+        const unsigned long long s[2] = {(unsigned long long)(h->step & 1 ? h->step - 1 : h->step), (unsigned long long)(h->step & 1 ? h->step : h->step + 1)};
+        HIP_TRY(h, hipMemcpyAsync(h->d_stepw, s, sizeof(s), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
-    const unsigned long long s = (unsigned long long)h->step;
-    HIP_TRY(h, hipMemcpyAsync(h->d_stepw + (h->step & 1), &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
 }
 
