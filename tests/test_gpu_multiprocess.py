@@ -1,0 +1,100 @@
+"""GPU suite: the sharded protocol across REAL processes with the HIP engine.  One GPU is all a test box has, so the
+ranks share device 0 (RCCL refuses two ranks on one GPU); the per-step exchange of the proposal bytes therefore goes
+through host copies and torch.distributed `gloo` instead of the in-place RCCL all-gather -- everything else is the
+production path: one process per rank, a `world`-sharded aps_handle each, aps_propose -> exchange -> aps_commit,
+caller-owned exchange buffer (aps_bind_exchange_buffer).  Every rank must end in the state of a single-handle run,
+in both formulations, and in the lattice formulation with identical field arrays."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case():
+    from oracle.gillespie_numpy import LatticeGasParams
+    par = LatticeGasParams.from_kwargs(L=3000, xlim=1.0, rate_diffusion=0.8, rate_active=4.0, beta=1.2, scale_rates=False,
+                                       local_kernel_sigma=0.01, site_capacity=2, anchor_positions=[0.4], anchor_radius=0.05,
+                                       k_on=2.0, k_off=1.0, k_exit=0.5)
+    rng = np.random.default_rng(23)
+    n = 2777
+    pos = rng.permutation(rng.choice(np.repeat(np.arange(3000), 2), size=n, replace=False)).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=n)
+    return par, pos, spin
+
+
+def _handle(capi, par, n, method, rank=0, world=1):
+    return capi.Handle(L=par.L, K=par.K, periodic=par.periodic, sigma_grid=par.sigma_grid, rate_diffusion=par.rate_diffusion,
+                       rate_active=par.rate_active, beta=[par.beta], dt=0.03, seed=99, n_particles=n, minus_anchor=par.minus_anchor,
+                       immobilize=par.immobilize_when_anchored, suppress_flip=par.suppress_flip_when_bound, k_on=par.k_on,
+                       k_off=par.k_off, k_exit=par.k_exit, anchor_mask=par.is_anchor_site, rank=rank, world=world, method=method)
+
+
+def _worker(rank, world, port, nsteps, method, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        capi = importlib.import_module(PKG + ".capi")
+        par, pos, spin = _case()
+        h = _handle(capi, par, len(pos), method, rank, world)
+        h.set_state(pos, spin)
+        dev = torch.device("cuda", 0)
+        _, total, off, mine = h.exchange_buffer()
+        buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        h.bind_exchange_buffer(buf.data_ptr(), total)
+        gathered = [torch.zeros(mine, dtype=torch.uint8) for _ in range(world)]
+        for _ in range(nsteps):
+            h.propose()
+            dist.all_gather(gathered, buf[off:off + mine].cpu())          # the copy waits for the propose kernels
+            buf.copy_(torch.cat(gathered))
+            h.commit()
+        torch.cuda.synchronize()
+        p, s, b, a = h.get_state()
+        extra = {}
+        if method == "lattice":
+            W, S, occ = h.get_lattice()
+            extra = dict(W=W, S=S, occ=occ)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=p, spin=s, bound=b, alive=a, exits=h.exits(), **extra)
+        h.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["lattice", "pairs"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_engine_across_processes(tmp_path, world, method):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    capi = importlib.import_module(PKG + ".capi")
+    nsteps = 60
+    port = 29700 + (os.getpid() % 1500) + 7 * world + (3 if method == "pairs" else 0)
+    mp.spawn(_worker, args=(world, port, nsteps, method, str(tmp_path)), nprocs=world, join=True)
+    par, pos, spin = _case()
+    single = _handle(capi, par, len(pos), method)
+    try:
+        single.set_state(pos, spin)
+        single.step(nsteps)
+        want = single.get_state()
+        want_exits = single.exits()
+        want_lat = single.get_lattice() if method == "lattice" else None
+    finally:
+        single.close()
+    assert (want[3] == 0).any(), "the case should exercise exits"
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        for key, w in zip(("pos", "spin", "bound", "alive"), want):
+            assert np.array_equal(got[key], w), (r, key)
+        assert np.array_equal(got["exits"], want_exits)
+        if want_lat is not None:
+            for key, w in zip(("W", "S", "occ"), want_lat):
+                assert np.array_equal(got[key], w), (r, key)
