@@ -231,36 +231,73 @@ def main():
     if sharded_path:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        device = int(os.environ.get("APS_BENCH_DEVICE", local_rank))   # rehearsals put several ranks on one GPU
+        torch.cuda.set_device(device)
         with stdout_to_stderr():                             # gloo announces its connections on stdout
             dist.init_process_group("gloo")                  # rendezvous / barriers only; the data path is RCCL below
-        h = make_handle(capi, w, device=local_rank, rank=rank, world=world, method=args.method)
+        h = make_handle(capi, w, device=device, rank=rank, world=world, method=args.method)
         h.set_state(pos, spin)
-        # preferred: the library all-gathers the proposal bytes itself (ncclAllGather on its stream, no Python per step)
-        ok, path = 1, "in-library RCCL all-gather"
-        try:
-            with stdout_to_stderr():
-                ids = [capi.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                h.comm_init(ids[0])
-                h.step(1)                                    # first collective (lazy channel setup) also under the redirect
-        except Exception as exc:                             # noqa: BLE001
-            ok = 0
-            print(f"[rank {rank}] in-library RCCL unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            run = h.step
-        else:                                                # every rank takes the fallback together
+
+        def all_agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        # The exchange of the proposal bytes, in order of preference (APS_BENCH_EXCHANGE forces one):
+        #   rccl        the library all-gathers itself (ncclAllGather on its stream, no Python per step)
+        #   torch-nccl  torch.distributed backend "nccl" (= RCCL) on a torch tensor bound to the library
+        #   gloo-host   host copies + gloo: always works (even with several ranks on one GPU); slow, last resort
+        forced = os.environ.get("APS_BENCH_EXCHANGE", "")
+        run, path = None, ""
+        if forced in ("", "rccl"):
+            ok = True
+            try:
+                with stdout_to_stderr():
+                    ids = [capi.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    h.comm_init(ids[0])
+                    h.step(1)                                # first collective (lazy channel setup) also under the redirect
+            except Exception as exc:                         # noqa: BLE001
+                ok = False
+                print(f"[rank {rank}] in-library RCCL unavailable ({exc})", file=sys.stderr)
+            if all_agree(ok):
+                run, path = h.step, "in-library RCCL all-gather"
+            elif ok:                                         # this rank has a communicator the others lack: start over without it
+                h.close()
+                h = make_handle(capi, w, device=device, rank=rank, world=world, method=args.method)
+                h.set_state(pos, spin)
+        if run is None and forced in ("", "rccl", "torch-nccl"):
             sharded = importlib.import_module(PKG + ".sharded")
-            path = "torch.distributed nccl all_gather_into_tensor"
-            with stdout_to_stderr():
-                group = dist.new_group(backend="nccl")
-                stepper = sharded.ShardedStepper(sharded.HipEngine(h, torch.device("cuda", local_rank)), group=group)
-                stepper.step(1)
+            ok, stepper = True, None
+            try:
+                with stdout_to_stderr():
+                    group = dist.new_group(backend="nccl")
+                    stepper = sharded.ShardedStepper(sharded.HipEngine(h, torch.device("cuda", device)), group=group)
+                    stepper.step(1)
+                    torch.cuda.synchronize()
+            except Exception as exc:                         # noqa: BLE001
+                ok = False
+                print(f"[rank {rank}] torch.distributed nccl unavailable ({exc})", file=sys.stderr)
+            if all_agree(ok):
+                path = "torch.distributed nccl all_gather_into_tensor"
+
+                def run(n, stepper=stepper):
+                    stepper.step(n)
+                    torch.cuda.synchronize()
+        if run is None:
+            path = "host copies + torch.distributed gloo (fallback: no RCCL between these ranks)"
+            _, total, off, mine = h.exchange_buffer()
+            buf = torch.zeros(total, dtype=torch.uint8, device=torch.device("cuda", device))
+            h.set_stream(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
+            h.bind_exchange_buffer(buf.data_ptr(), total)
+            gathered = [torch.zeros(mine, dtype=torch.uint8) for _ in range(world)]
 
             def run(n):
-                stepper.step(n)
+                for _ in range(int(n)):
+                    h.propose()
+                    dist.all_gather(gathered, buf[off:off + mine].cpu())
+                    buf.copy_(torch.cat(gathered))
+                    h.commit()
                 torch.cuda.synchronize()
         run(args.warmup)
         dist.barrier()
