@@ -10,13 +10,14 @@ from .particle_system import ParticleSystem, run_batched, run_batched_statistics
 
 
 def sweep_over_betas(beta_values, n_runs_per_beta=10, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
-                     rng_seeds=None, keep_outputs=False, on_device=False):
+                     rng_seeds=None, keep_outputs=False, on_device=False, dynamics="sync"):
     """Returns a dict with the keys the reference saves (`beta_values, means, stds, ses, D_means, D_ses, m_means,
     m_stds, m_ses, rho_means, rho_ses, block_means, block_ses`, ..._sweep_beta.py:952-968) plus `raw_by_beta`.
     `rng_seeds[b][r]` seeds the initial condition of run r at beta b (None: unseeded, like the reference).
     `on_device=True` evaluates the observables from integer sums taken on the GPU at each observation time
     (run_batched_statistics; needs k_exit = 0) instead of from the M x L arrays of `run()`; `run_kwargs` may then
-    only hold T and obs_dt."""
+    only hold T and obs_dt.  `dynamics="exact"` runs the reference's event-by-event dynamics resident on the GPU
+    (gillespie.run_batched_exact / run_batched_exact_statistics) instead of the fixed-dt scheme."""
     ps_kwargs, init_kwargs, run_kwargs = dict(ps_kwargs or {}), dict(init_kwargs or {}), dict(run_kwargs or {})
     systems, owner = [], []
     for bi, beta in enumerate(beta_values):
@@ -24,11 +25,22 @@ def sweep_over_betas(beta_values, n_runs_per_beta=10, ps_kwargs=None, init_kwarg
             rng = None if rng_seeds is None else np.random.default_rng(int(rng_seeds[bi][r]))
             systems.append(ParticleSystem(beta=beta, rng=rng, **ps_kwargs, **init_kwargs))
             owner.append(bi)
+    if dynamics not in ("sync", "exact"):
+        raise ValueError("dynamics must be 'sync' or 'exact'")
     if on_device:
         if keep_outputs:
             raise ValueError("on_device=True keeps no per-run outputs")
         outs = None
-        rows = run_batched_statistics(systems, **{k: v for k, v in run_kwargs.items() if k in ("T", "obs_dt")})
+        slim = {k: v for k, v in run_kwargs.items() if k in ("T", "obs_dt")}
+        if dynamics == "exact":
+            from .gillespie import run_batched_exact_statistics
+            rows = run_batched_exact_statistics(systems, **slim)
+        else:
+            rows = run_batched_statistics(systems, **slim)
+    elif dynamics == "exact":
+        from .gillespie import run_batched_exact
+        outs = run_batched_exact(systems, want_m_local=False, **run_kwargs)
+        rows = [observables.run_observables(out, ps.L, ps.dx) for ps, out in zip(systems, outs)]
     else:
         outs = run_batched(systems, **run_kwargs)
         rows = [observables.run_observables(out, ps.L, ps.dx) for ps, out in zip(systems, outs)]

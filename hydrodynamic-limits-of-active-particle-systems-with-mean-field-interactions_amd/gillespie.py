@@ -146,3 +146,43 @@ def run_batched_exact(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var
                      "exit_times": [float(t) for t in ex[:, 0]], "exit_positions": [int(x) for x in ex[:, 1]]})
     first.kernel_ms = r["kernel_ms"]
     return outs
+
+
+def run_batched_exact_statistics(systems, T=10.0, obs_dt=0.01):
+    """The sweep drivers' per-run observables (observables.DeviceObservables: v_eff, D_eff, mean magnetisation, front
+    density, blocking probability) for many systems under the exact dynamics, from the integer sums the event-loop
+    kernel records at every observation -- no state arrays leave the GPU.  Needs k_exit = 0 like every reference sweep."""
+    from . import observables
+    from .particle_system import _SHAPE_ATTRS
+    first = systems[0]
+    for ps in systems[1:]:
+        for k in _SHAPE_ATTRS:
+            if getattr(ps, k) != getattr(first, k):
+                raise ValueError(f"run_batched_exact_statistics: systems differ in {k}")
+    if first.k_exit:
+        raise ValueError("run_batched_exact_statistics needs k_exit = 0")
+    inits = [ps.init_particles() for ps in systems]
+    if len({len(p) for p, _ in inits}) != 1:
+        raise ValueError("run_batched_exact_statistics: the blocking threshold is shared, so all systems need the same particle number")
+    seed = first.seed if first.seed is not None else int(first.rng.random() * 2.0 ** 53)
+    times_obs = np.arange(0.0, T, obs_dt)
+    acc0 = observables.DeviceObservables(times_obs, first.L, first.dx, first.K)
+    front_lo = np.array([acc0.front_range(s)[0] for s in range(first.L)], np.int32)
+    r = run_raw(L=first.L, K=first.K, periodic=first.periodic, sigma_grid=first._sigma_grid, rate_diffusion=first.rate_diffusion,
+                rate_active=first.rate_active, betas=[float(ps.beta) for ps in systems], states=inits, times_obs=times_obs, T=T,
+                seed=seed, minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
+                suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,
+                k_off=first.k_off, k_exit=0.0, anchor_mask=first.is_anchor_site, want_states=False, x_wall=acc0.x_wall,
+                ref_obs=acc0.start, front_lo=front_lo, block_table=acc0.block_table(len(inits[0][0])), device=first.device)
+    rows = []
+    for s, ps in enumerate(systems):
+        if int(r["n_recorded"][s]) < len(times_obs):
+            raise RuntimeError("a system passed T before its last observation time (choose T beyond the last observation)")
+        acc = observables.DeviceObservables(times_obs, first.L, first.dx, first.K)
+        for k in range(len(times_obs)):
+            sums = dict(zip(SCALARS, (int(v) for v in r["scalars"][s, k])))
+            acc.add(k, sums, sums["n_front"] if k >= acc.start and sums["max_pos"] >= 0 else None)
+        rows.append(acc.result())
+        ps.n_events = int(r["n_events"][s])
+    first.kernel_ms = r["kernel_ms"]
+    return rows

@@ -189,3 +189,20 @@ def test_particle_system_mode_gillespie_gpu_contract():
                            local_kernel_sigma=0.02, site_capacity=2, k_on=0.0, k_off=0.0, k_exit=0.0, rng=np.random.default_rng(3),
                            seed=77, mode="gillespie_gpu").run(T=2.0, obs_dt=0.1)
     assert all(np.array_equal(a, b) for a, b in zip(out["pos_list"], again["pos_list"]))      # seeded runs repeat
+
+
+def test_exact_sweep_statistics_from_device_sums_equal_full_outputs():
+    """sweep_over_betas(dynamics="exact"): the observables evaluated from the in-kernel integer sums equal the same
+    observables on the full outputs of the same (seeded, hence identical) runs."""
+    ens = importlib.import_module(PKG + ".ensemble")
+    kw = dict(L=500, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, scale_rates=False, local_kernel_sigma=0.01,
+              site_capacity=2, k_on=0.0, k_off=0.0, k_exit=0.0, seed=909)
+    betas, seeds = [0.0, 1.5, 3.0], [[11, 12], [21, 22], [31, 32]]
+    run_kw = dict(T=10.05, obs_dt=0.25)
+    full = ens.sweep_over_betas(betas, 2, ps_kwargs=kw, init_kwargs=dict(init="fixed", N=260), run_kwargs=run_kw, rng_seeds=seeds,
+                                dynamics="exact")
+    slim = ens.sweep_over_betas(betas, 2, ps_kwargs=kw, init_kwargs=dict(init="fixed", N=260), run_kwargs=run_kw, rng_seeds=seeds,
+                                dynamics="exact", on_device=True)
+    for key in ("means", "stds", "ses", "D_means", "D_ses", "m_means", "m_stds", "m_ses", "rho_means", "rho_ses", "block_means", "block_ses"):
+        np.testing.assert_allclose(slim[key], full[key], rtol=1e-8, atol=1e-11, err_msg=key)
+    assert np.all(np.isfinite(full["means"])) and np.all(full["block_means"] >= 0.0)
