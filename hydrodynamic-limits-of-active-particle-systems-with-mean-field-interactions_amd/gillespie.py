@@ -162,18 +162,20 @@ def run_batched_exact_statistics(systems, T=10.0, obs_dt=0.01):
     if first.k_exit:
         raise ValueError("run_batched_exact_statistics needs k_exit = 0")
     inits = [ps.init_particles() for ps in systems]
-    if len({len(p) for p, _ in inits}) != 1:
-        raise ValueError("run_batched_exact_statistics: the blocking threshold is shared, so all systems need the same particle number")
     seed = first.seed if first.seed is not None else int(first.rng.random() * 2.0 ** 53)
     times_obs = np.arange(0.0, T, obs_dt)
     acc0 = observables.DeviceObservables(times_obs, first.L, first.dx, first.K)
+    tables = [acc0.block_table(len(p)) for p, _ in inits]      # the blocking threshold depends on the particle number
+    if any(not np.array_equal(t, tables[0]) for t in tables[1:]):
+        raise ValueError("run_batched_exact_statistics: the systems' particle numbers give different blocking thresholds; "
+                         "run them in separate batches")
     front_lo = np.array([acc0.front_range(s)[0] for s in range(first.L)], np.int32)
     r = run_raw(L=first.L, K=first.K, periodic=first.periodic, sigma_grid=first._sigma_grid, rate_diffusion=first.rate_diffusion,
                 rate_active=first.rate_active, betas=[float(ps.beta) for ps in systems], states=inits, times_obs=times_obs, T=T,
                 seed=seed, minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
                 suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,
                 k_off=first.k_off, k_exit=0.0, anchor_mask=first.is_anchor_site, want_states=False, x_wall=acc0.x_wall,
-                ref_obs=acc0.start, front_lo=front_lo, block_table=acc0.block_table(len(inits[0][0])), device=first.device)
+                ref_obs=acc0.start, front_lo=front_lo, block_table=tables[0], device=first.device)
     rows = []
     for s, ps in enumerate(systems):
         if int(r["n_recorded"][s]) < len(times_obs):
