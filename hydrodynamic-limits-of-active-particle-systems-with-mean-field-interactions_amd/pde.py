@@ -199,3 +199,31 @@ class IMEXPDE:
     def plot_individual(self, *args, **kwargs):
         raise NotImplementedError("plot_individual (matplotlib figures, reference :348-461) is presentation code "
                                   "outside the accelerated path")
+
+
+def sweep_over_betas(beta_values, n_runs=3, t_min=20.0, t_max=40.0, seeds=None, init_kwargs=None, **ctor_kwargs):
+    """The reference's PDE tracer sweep (IMEX_PDE_solver_run_sweep.py:7-75) as ONE launch: every (beta, run) pair is a
+    system with its own seeded initial condition.  Returns (v_mean, v_err, D_mean, D_err) per beta exactly as the
+    driver forms them: v = |nanmean(v_eff_series[t_min <= t <= t_max])|, D = nanmean(D_eff_series[...]), mean over runs,
+    err = std(ddof=1) / sqrt(n_runs)."""
+    init_kwargs = dict(init_kwargs or {})
+    betas, rp, rm, tx, ts = [], [], [], [], []
+    proto = None
+    for bi, beta in enumerate(beta_values):
+        for run in range(n_runs):
+            seed = run if seeds is None else seeds[bi][run]         # the reference seeds each run with its run index
+            s = IMEXPDE(beta=beta, seed=seed, record_fft=False, **ctor_kwargs)
+            s.initialize(**init_kwargs)
+            proto = proto or s
+            betas.append(float(beta)); rp.append(s.rho_p); rm.append(s.rho_m); tx.append(s.tracers_unwrapped); ts.append(s.tracer_state)
+    r = solve_batch_raw(L=proto.L, xlim=proto.xlim, dt=proto.dt, nsteps=proto.nsteps, gamma=proto.gamma, lam=proto.lam, betas=betas,
+                        bc=proto.bc, active_model=proto.active_model, gaussian_kernel=proto.gaussian_kernel,
+                        kernel_sigma=proto.kernel_sigma, snapshot_interval=proto.snapshot_interval, rho_p0=np.array(rp),
+                        rho_m0=np.array(rm), tracer_x0=np.array(tx), tracer_s0=np.array(ts), seed=proto.seed or 0,
+                        device=proto.device, want_snapshots=False)
+    t = np.linspace(0, proto.T, proto.nsteps + 1)
+    mask = (t >= t_min) & (t <= t_max)
+    v = np.abs(np.nanmean(r["v_eff_series"][:, mask], axis=1)).reshape(len(beta_values), n_runs)
+    D = np.nanmean(r["D_eff_series"][:, mask], axis=1).reshape(len(beta_values), n_runs)
+    root = np.sqrt(n_runs)
+    return (v.mean(axis=1), v.std(axis=1, ddof=1) / root, D.mean(axis=1), D.std(axis=1, ddof=1) / root, r["kernel_ms"])

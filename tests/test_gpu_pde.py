@@ -125,3 +125,36 @@ def test_pde_error_paths(pde):
     s.initialize(n_tracers=8)
     with pytest.raises(ValueError):
         s.solve()
+
+
+def test_tracer_sweep_reproduces_the_reference_s_recorded_results(pde):
+    """The reference keeps the results of its PDE tracer sweep as pasted numbers (plot_figs.py:6-9; fixture
+    g8_pde_sweep_published.json holds them as data).  The same sweep on the GPU -- 11 beta x 3 runs, 80 000 steps each,
+    one launch -- must reproduce the recorded v_eff(beta) within the run-to-run scatter the reference itself reports.
+    beta = 1.2 sits at the ordering transition (its recorded scatter is 10x the others'): only a loose bound there.
+
+    The recorded D_eff series (0.377 -> 0.201) is NOT what the shipped class computes: with its window of 0.05 time
+    units (IMEX_PDE_solver_class.py:238) the tracers are still ballistic between flips and D_eff = gamma +
+    lam^2 tau (1 - <s>^2) / 2 ~ 0.207 at beta = 0 -- the CPU oracle, bit-identical to the shipped code, gives 0.2069 --
+    so those numbers came from a longer window.  D is therefore checked against that short-window expression."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g8_pde_sweep_published.json")) as fh:
+        g = json.load(fh)
+    betas = np.linspace(0, 3, 11)
+    assert np.allclose(betas, g["beta_values"])
+    gamma, lam, tau = 0.2, 0.6, 0.05
+    v, v_err, D, D_err, ms = pde.sweep_over_betas(betas, n_runs=3, t_min=20.0, t_max=40.0, L=1000, T=40.0, dt=5e-4, gamma=gamma, lam=lam,
+                                                  bc="periodic", active_model="bidirectional", gaussian_kernel=True,
+                                                  kernel_sigma=1e5 - 10, snapshot_interval=50,
+                                                  init_kwargs=dict(mode="homogeneous", rho0=1.0, noise=0.3))
+    print("v", np.round(v, 4), "D", np.round(D, 4), f"kernel {ms / 1e3:.1f} s")
+    for i, beta in enumerate(betas):
+        if abs(beta - 1.2) < 1e-9:
+            assert 0.2 < v[i] < 0.45
+        elif beta < 1.0:                                        # |mean| of pure noise: a magnitude, not a signed mean
+            assert v[i] < 0.012, (beta, v[i])
+        else:
+            assert abs(v[i] - g["v_mean"][i]) <= 5 * np.hypot(v_err[i], g["v_err"][i]) + 2e-3, (beta, v[i], g["v_mean"][i])
+        want_D = gamma + lam ** 2 * tau * (1.0 - (v[i] / lam) ** 2) / 2.0
+        assert abs(D[i] - want_D) <= 5 * D_err[i] + 4e-3, (beta, D[i], want_D)
