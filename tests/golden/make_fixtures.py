@@ -464,6 +464,29 @@ def make_g6():
     _save("g6_pde.npz", dict(cases=cases, kw=G6_KW, init=dict(rho0=1.0, noise=0.2, n_tracers=300)), arrays)
 
 
+# --------------------------------------------------------------------------------------- g8
+def make_g8():
+    """The only simulation results the reference itself records: the number lists of plot_figs.py:6-9 (v_eff, D_eff and
+    their standard errors over beta of the PDE tracer sweep).  Read as DATA from the file's text; nothing is executed."""
+    import re
+    with open(os.path.join(REF, "plot_figs.py")) as fh:
+        text = fh.read()
+    out = {"provenance": "Numbers the reference holds as pasted results in plot_figs.py:6-9 (series plotted as 'Particle Sim'; by their values -- "
+                         "D -> gamma = 0.2, v -> lam = 0.6 -- they are the tracer sweep of IMEX_PDE_solver_run_sweep.py:7-75: L=1000, T=40, dt=5e-4, "
+                         "gamma=0.2, lam=0.6, periodic, bidirectional, gaussian_kernel=True, kernel_sigma=1e5-10, homogeneous init rho0=1 noise=0.3, "
+                         "1000 tracers, 3 runs per beta, window t in [20, 40], v = |nanmean v_eff|, D = nanmean D_eff, err = std(ddof=1)/sqrt(3)). "
+                         "Data only (tests/golden/make_fixtures.py g8). Note: the D series corresponds to a longer averaging window than the 0.05 "
+                         "of the shipped class (whose D_eff at beta=0 is 0.207, see tests/test_gpu_pde.py); only the v series is used as a parity target.",
+           "beta_values": [0.3 * i for i in range(11)]}
+    for key in ("v_mean", "v_err", "D_mean", "D_err"):
+        m = re.search(r"^%s\s*=\s*\[(.*?)\]" % key, text, re.M | re.S)
+        out[key] = [float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]
+        assert len(out[key]) == 11
+    with open(os.path.join(HERE, "g8_pde_sweep_published.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote g8_pde_sweep_published.json")
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or ["g1", "g2", "g3", "g5"]
     for t in todo:
