@@ -27,7 +27,6 @@
 
 namespace {
 
-constexpr int NT = 256;
 std::string g_gil_err;
 enum { F_PLUS = 1, F_BOUND = 2, F_ALIVE = 4 };
 enum { GS_N = 0, GS_SPIN, GS_POS, GS_WALL, GS_MAXPOS, GS_FRONT, GS_ATTEMPT, GS_BLOCKED, GS_DISP, GS_DISP2, GS_NDISP, GS_EVENTS };
@@ -45,13 +44,45 @@ struct GilArgs {
     int32_t *n_recorded; long long *n_events; double *t_final, *exits; int32_t *n_exits;
 };
 
+template <int NT>
 __device__ inline long long wg_sum_ll(long long v, long long *red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    long long s = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
+    return s;
+}
+
+// value of the lane n below within the same row of 16 lanes (0.0 when that lane is outside the row): two 32-bit DPP moves
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x110 | N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x110 | N, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// inclusive scan over one wavefront without touching LDS: Hillis-Steele inside the rows of 16 lanes (DPP), then the three
+// row totals are added to the rows above them
+__device__ __forceinline__ double wave_scan_inclusive(double v) {
+    v += row_shr<1>(v); v += row_shr<2>(v); v += row_shr<4>(v); v += row_shr<8>(v);
+    const int row = (threadIdx.x & 63) >> 4;
+    const double t0 = read_lane(v, 15), t1 = read_lane(v, 31), t2 = read_lane(v, 47);
+    double add = 0.0;
+    if (row > 0) add = t0;
+    if (row > 1) add += t1;
+    if (row > 2) add += t2;
+    return v + add;
 }
 
 // weight of source site p seen from site x, images folded in (same lookups as the stepper's field kernels)
@@ -63,16 +94,20 @@ __device__ inline double site_weight(const Model &M, const double *tab, int tlen
     return tab[min(d, tlen)] + tab[min(min(s, 2 * L - s), tlen)];
 }
 
+// NT = threads per system: one wavefront (no real barriers, six systems per CU by LDS) for small systems, four for large ones
+template <int NT>
 __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
     extern __shared__ double lds[];
     const Model &M = a.m;
     const int L = M.L, K = M.K, t = threadIdx.x, sys = blockIdx.x, ncap = a.p.n_cap, nobs = a.p.n_obs;
     double *W = lds, *S = W + L, *tab = S + L, *rate = tab + ((a.tlen + 2) & ~1), *red = rate + ncap + (ncap & 1);
     double *tinc = red + 8;                                   // [NT] inclusive scan of the threads' rate sums
-    long long *redl = reinterpret_cast<long long *>(tinc + NT);   // [8]
+    double *draws = tinc + NT;                                // [NT][4] -log1p(-u0), u1, u2, u3 of the next NT events
+    long long *redl = reinterpret_cast<long long *>(draws + 4 * NT);   // [8]
     int *pos = reinterpret_cast<int *>(redl + 8);             // [ncap]
     int *ref = pos + ncap;                                    // [ncap] positions at the reference observation
-    int *ctl = ref + ncap;                                    // [16] broadcast slots
+    int *work = ref + ncap;                                   // [ncap] particles whose rates are re-evaluated before this event
+    int *ctl = work + ncap;                                   // [16] broadcast slots
     uint8_t *flg = reinterpret_cast<uint8_t *>(ctl + 16);     // [ncap]
     uint8_t *occ = flg + ((ncap + 15) & ~15);                 // [L] particles per site
     uint8_t *occp = occ + ((L + 15) & ~15);                   // [L] plus particles per site (blocking table)
@@ -87,6 +122,7 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
         flg[i] = live ? (uint8_t)(F_ALIVE | (a.sigma0[(size_t)sys * ncap + i] > 0 ? F_PLUS : 0) |
                                   ((a.bound0 && a.bound0[(size_t)sys * ncap + i]) ? F_BOUND : 0)) : 0;
         ref[i] = -1;
+        rate[i] = 0.0;                                         // empty and departed slots keep rate zero
     }
     __syncthreads();
     if (t == 0) for (int i = 0; i < n_init; ++i) { occ[pos[i]]++; if (flg[i] & F_PLUS) occp[pos[i]]++; }
@@ -105,7 +141,7 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
     if (!M.field_mode) {
         long long ls = 0, ln = 0;
         for (int i = t; i < n_init; i += NT) { ls += (flg[i] & F_PLUS) ? 1 : -1; ln += 1; }
-        gsum_s = wg_sum_ll(ls, redl); gsum_n = wg_sum_ll(ln, redl);
+        gsum_s = wg_sum_ll<NT>(ls, redl); gsum_n = wg_sum_ll<NT>(ln, redl);
     }
     double tnow = 0.0;
     long long n_ev = 0;
@@ -139,14 +175,16 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
         __syncthreads();
         if ((t & 63) == 0) redl[4 + (t >> 6)] = mx;
         __syncthreads();
-        mx = max(max(redl[4], redl[5]), max(redl[6], redl[7]));
+        mx = redl[4];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) mx = max(mx, redl[4 + w]);
         if (a.front_lo && mx >= 0) {
             const int lo = a.front_lo[mx];
             for (int i = t; i < ncap; i += NT) if ((flg[i] & F_ALIVE) && pos[i] >= lo) v[GS_FRONT] += 1;
         }
         for (int q = 0; q < GIL_NSCALARS; ++q) {
             if (q == GS_MAXPOS || q == GS_EVENTS) continue;
-            const long long s = wg_sum_ll(v[q], redl);
+            const long long s = wg_sum_ll<NT>(v[q], redl);
             if (t == 0 && a.scalars) a.scalars[((size_t)sys * nobs + k) * GIL_NSCALARS + q] = s;
         }
         if (t == 0 && a.scalars) {
@@ -158,68 +196,131 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
 
     record(0);                                                 // ref :489-508
     k_obs = 1;
+    double t_next = nobs > 1 ? a.times[1] : INFINITY;          // next observation time (kept in a register: no load per event)
+#ifdef APS_STAMPS
+    unsigned long long st[5] = {0, 0, 0, 0, 0}, s0 = __builtin_amdgcn_s_memtime();
+#define GSTAMP(k) { const unsigned long long s1_ = __builtin_amdgcn_s_memtime(); st[k] += s1_ - s0; s0 = s1_; }
+#else
+#define GSTAMP(k)
+#endif
+    long long ev_base = 0;                                     // first event of the block of draws held in LDS
+    bool dirty_all = true;                                     // first event: every rate is evaluated
+    int dirty_a = 0, dirty_b = 0;
+    const int dirty_reach = (M.field_mode ? a.tlen - 1 : 0) + 1;
     while (tnow < a.p.T && k_obs < nobs && n_ev < a.p.max_events) {
-        // ---- A: rates (ref :254-352)
-        double mine = 0.0;
-        for (int i = c0; i < c1; ++i) {
-            double r = 0.0;
-            const uint8_t f = flg[i];
-            if (f & F_ALIVE) {
-                const int p = pos[i];
-                double w, s;
-                if (M.field_mode) { w = W[p]; s = S[p]; } else { w = (double)gsum_n; s = (double)gsum_s; }
-                double mloc = 0.0;
-                if (w > 0.0) { mloc = s / w; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
-                int l = p - 1, rr = p + 1;
-                if (M.periodic) { l = l < 0 ? l + L : l; rr = rr >= L ? rr - L : rr; }
-                const Channels c = channels(M, a.anchor ? a.anchor[p] != 0 : false, p, (f & F_PLUS) ? 1 : -1, (f & F_BOUND) != 0, mloc, beta,
-                                            occ[p], l >= 0 ? occ[l] : 0, rr < L ? occ[rr] : 0);
-                r = c.total;
+        // ---- A: rates (ref :254-352).  The reference recomputes every particle's rates before every event; here only
+        // the particles whose inputs the last event changed are re-evaluated (field within the table's reach of the
+        // event's sites, occupancy of the neighbouring sites) -- the others' rates are the values already in LDS.
+        // (1) every thread lists its particles that need it (lanes that find none do not hold up the others: the
+        //     expensive rate evaluation then runs once over the compacted list, a lane per listed particle)
+        int nwork = 0;
+        if (NT == 64) {                                        // one wavefront: ballot + mbcnt compaction, no LDS counter
+            for (int k = 0; k < a.chunk; ++k) {
+                const int i = c0 + k;
+                bool redo = i < c1 && (flg[i] & F_ALIVE);      // the rate of a particle that left was zeroed when it left
+                if (redo && !dirty_all) {
+                    int d0 = pos[i] - dirty_a, d1 = pos[i] - dirty_b;
+                    d0 = d0 < 0 ? -d0 : d0; d1 = d1 < 0 ? -d1 : d1;
+                    if (M.periodic) { d0 = min(d0, L - d0); d1 = min(d1, L - d1); }
+                    redo = min(d0, d1) <= dirty_reach;
+                }
+                const unsigned long long m = __ballot(redo);
+                if (redo) work[nwork + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
+                nwork += __popcll(m);
             }
-            rate[i] = r;
-            mine += r;
+        } else {
+            if (t == 0) ctl[6] = 0;
+            __syncthreads();
+            for (int i = c0; i < c1; ++i) {
+                if (!(flg[i] & F_ALIVE)) continue;
+                bool redo = dirty_all;
+                if (!redo) {
+                    int d0 = pos[i] - dirty_a, d1 = pos[i] - dirty_b;
+                    d0 = d0 < 0 ? -d0 : d0; d1 = d1 < 0 ? -d1 : d1;
+                    if (M.periodic) { d0 = min(d0, L - d0); d1 = min(d1, L - d1); }
+                    redo = min(d0, d1) <= dirty_reach;
+                }
+                if (redo) work[atomicAdd(&ctl[6], 1)] = i;
+            }
+            __syncthreads();
+            nwork = ctl[6];
         }
-        double inc = mine;                                     // inclusive scan over the threads
+        __syncthreads();
+        for (int j = t; j < nwork; j += NT) {
+            const int i = work[j], p = pos[i];
+            const uint8_t f = flg[i];
+            double w, s;
+            if (M.field_mode) { w = W[p]; s = S[p]; } else { w = (double)gsum_n; s = (double)gsum_s; }
+            double mloc = 0.0;
+            if (w > 0.0) { mloc = s / w; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+            int l = p - 1, rr = p + 1;
+            if (M.periodic) { l = l < 0 ? l + L : l; rr = rr >= L ? rr - L : rr; }
+            rate[i] = channels(M, a.anchor ? a.anchor[p] != 0 : false, p, (f & F_PLUS) ? 1 : -1, (f & F_BOUND) != 0, mloc, beta,
+                               occ[p], l >= 0 ? occ[l] : 0, rr < L ? occ[rr] : 0).total;
+        }
+        __syncthreads();
+        double mine = 0.0;
+        for (int i = c0; i < c1; ++i) mine += rate[i];
+        double inc;                                            // inclusive scan over the threads
+        if (NT == 64) inc = wave_scan_inclusive(mine);
+        else {
+            inc = mine;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(inc, off); if ((t & 63) >= off) inc += o; }
-        __syncthreads();
-        if ((t & 63) == 63) red[t >> 6] = inc;
-        __syncthreads();
-        double before = 0.0;
-        for (int w = 0; w < (t >> 6); ++w) before += red[w];
-        inc += before;
+            for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(inc, off); if ((t & 63) >= off) inc += o; }
+            __syncthreads();
+            if ((t & 63) == 63) red[t >> 6] = inc;
+            __syncthreads();
+            double before = 0.0;
+            for (int w = 0; w < (t >> 6); ++w) before += red[w];
+            inc += before;
+        }
         tinc[t] = inc;
+        GSTAMP(0)
+        // ---- B: draws (ref :358-362): the numbers of NT consecutive events are produced together, a lane per event
+        if ((n_ev - ev_base) >= NT || n_ev == 0) {
+            ev_base = n_ev;
+            const long long evn = n_ev + t;
+            double u0, u1, u2, u3;
+            if (a.uniforms) {
+                const bool in = evn < a.p.max_events;
+                const double *src = a.uniforms + ((size_t)sys * a.p.max_events + (in ? evn : 0)) * 4;
+                u0 = in ? src[0] : 0.0; u1 = in ? src[1] : 0.0; u2 = in ? src[2] : 0.0; u3 = in ? src[3] : 0.0;
+            } else {
+                uint32_t x[4], y[4];
+                philox4x32_10((uint32_t)evn, (uint32_t)(evn >> 32), (uint32_t)sys, 0x47494C31u, M.seed_lo, M.seed_hi, x);
+                philox4x32_10((uint32_t)evn, (uint32_t)(evn >> 32), (uint32_t)sys, 0x47494C32u, M.seed_lo, M.seed_hi, y);
+                u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
+                u1 = ((double)(x[2] >> 5) * 67108864.0 + (double)(x[3] >> 6)) * 0x1.0p-53;
+                u2 = ((double)(y[0] >> 5) * 67108864.0 + (double)(y[1] >> 6)) * 0x1.0p-53;
+                u3 = ((double)(y[2] >> 5) * 67108864.0 + (double)(y[3] >> 6)) * 0x1.0p-53;
+            }
+            draws[4 * t] = -log1p(-u0); draws[4 * t + 1] = u1; draws[4 * t + 2] = u2; draws[4 * t + 3] = u3;
+        }
+        if (t == 0) ctl[0] = NT;                               // first thread whose running sum exceeds the target
         __syncthreads();
         const double R = tinc[NT - 1];
         if (!(R > 0.0)) { tnow = INFINITY; break; }           // ref :355: tau = inf ends the loop
-        // ---- B: draws (ref :358-362)
-        double u[4];
-        if (a.uniforms) {
-            const double *src = a.uniforms + ((size_t)sys * a.p.max_events + n_ev) * 4;
-            u[0] = src[0]; u[1] = src[1]; u[2] = src[2]; u[3] = src[3];
-        } else {
-            uint32_t x[4], y[4];
-            philox4x32_10((uint32_t)n_ev, (uint32_t)(n_ev >> 32), (uint32_t)sys, 0x47494C31u, M.seed_lo, M.seed_hi, x);
-            philox4x32_10((uint32_t)n_ev, (uint32_t)(n_ev >> 32), (uint32_t)sys, 0x47494C32u, M.seed_lo, M.seed_hi, y);
-            u[0] = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
-            u[1] = ((double)(x[2] >> 5) * 67108864.0 + (double)(x[3] >> 6)) * 0x1.0p-53;
-            u[2] = ((double)(y[0] >> 5) * 67108864.0 + (double)(y[1] >> 6)) * 0x1.0p-53;
-            u[3] = ((double)(y[2] >> 5) * 67108864.0 + (double)(y[3] >> 6)) * 0x1.0p-53;
-        }
-        const double tau = (1.0 / R) * -log1p(-u[0]);
+        const double *dr = draws + 4 * (int)(n_ev - ev_base);
+        const double u[4] = {0.0, dr[1], dr[2], dr[3]};
+        const double tau = (1.0 / R) * dr[0];
         const double target = u[1] * R;
-        if (t == 0) ctl[0] = NT;                               // first thread whose running sum exceeds the target
-        __syncthreads();
-        if (inc > target && mine > 0.0) atomicMin(&ctl[0], t);
-        __syncthreads();
-        int tsel = ctl[0];
-        if (tsel >= NT) {                                      // target rounded past the total: last thread that has any rate
-            if (t == 0) ctl[1] = -1;
+        int tsel;
+        if (NT == 64) {                                        // one wavefront: the choice is a ballot
+            const unsigned long long above = __ballot(inc > target && mine > 0.0), any = __ballot(mine > 0.0);
+            tsel = above ? __builtin_ctzll(above) : 63 - __builtin_clzll(any);   // target rounded past the total: last lane with any rate
+        } else {
+            if (inc > target && mine > 0.0) atomicMin(&ctl[0], t);
             __syncthreads();
-            if (mine > 0.0) atomicMax(&ctl[1], t);
-            __syncthreads();
-            tsel = ctl[1];
+            tsel = ctl[0];
+            if (tsel >= NT) {                                  // target rounded past the total: last thread that has any rate
+                if (t == 0) ctl[1] = -1;
+                __syncthreads();
+                if (mine > 0.0) atomicMax(&ctl[1], t);
+                __syncthreads();
+                tsel = ctl[1];
+            }
         }
+        GSTAMP(1)
         // ---- C: the chosen thread picks the particle and applies the event (ref :363-446)
         if (t == tsel) {
             double run = tinc[t] - mine;
@@ -261,6 +362,7 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
                 if (plus) occp[p]--; else occp[p]++;
             } else if (kind == 3) {
                 f &= (uint8_t)~F_ALIVE;
+                rate[i] = 0.0;
                 occ[p]--; if (plus) occp[p]--;
                 if (a.exits && n_exit < ncap) {
                     double *row = a.exits + ((size_t)sys * ncap + n_exit) * 3;
@@ -271,9 +373,14 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
             ctl[2] = kind; ctl[3] = p; ctl[4] = to; ctl[5] = plus ? 1 : -1;
         }
         __syncthreads();
+        GSTAMP(2)
         // ---- D: the event's change of the smoothed histograms
         const int kind = ctl[2], p_old = ctl[3], p_new = ctl[4], sg = ctl[5];
         if (kind == 3) n_exit += 1;
+        // whose rates must be re-evaluated before the next event: everybody when the global mean moved, otherwise the
+        // particles within the table's reach (+1 site for the occupancy of neighbours) of the event's sites
+        dirty_a = p_old; dirty_b = p_new;
+        dirty_all = !M.field_mode && (kind == 2 || kind == 3);
         if (!M.field_mode) {
             if (kind == 2) gsum_s -= 2 * sg;
             else if (kind == 3) { gsum_s -= sg; gsum_n -= 1; }
@@ -299,12 +406,17 @@ __global__ __launch_bounds__(NT) void gil_kernel(const GilArgs a) {
             }
         }
         __syncthreads();
+        GSTAMP(3)
         // ---- E: time and observations (ref :514-538)
         n_ev += 1;
         tnow += tau;
         if (tnow > a.p.T) break;
-        while (k_obs < nobs && a.times[k_obs] <= tnow) { record(k_obs); ++k_obs; }
+        while (k_obs < nobs && t_next <= tnow) { record(k_obs); ++k_obs; t_next = k_obs < nobs ? a.times[k_obs] : INFINITY; }
+        GSTAMP(4)
     }
+#ifdef APS_STAMPS
+    if (t == 0 && sys == 0 && a.exits) for (int k = 0; k < 5; ++k) a.exits[k] = (double)st[k];   // diagnostic build only
+#endif
     if (t == 0) {
         if (a.n_recorded) a.n_recorded[sys] = k_obs;
         if (a.n_events) a.n_events[sys] = n_ev;
@@ -364,6 +476,7 @@ int gil_run_batch(const gil_params *p, const int32_t *n0, const int32_t *pos0, c
     std::vector<double> table; int tlen = 0, q = 0;
     weight_table(p->sigma_grid, L, p->K, p->periodic != 0, table, tlen, q);
     GilArgs a{};
+    const int NT = ncap <= 1024 ? 64 : 256;                   // one wavefront per system while a lane owns at most 16 particles
     a.p = *p; a.tlen = tlen; a.chunk = (ncap + NT - 1) / NT;
     Model &M = a.m;
     M.L = L; M.K = p->K; M.periodic = p->periodic ? 1 : 0; M.field_mode = p->sigma_grid > 0.0 ? 1 : 0;
@@ -388,16 +501,18 @@ int gil_run_batch(const gil_params *p, const int32_t *n0, const int32_t *pos0, c
     if (n_events) { a.n_events = d.alloc<long long>((size_t)S); if (!a.n_events) { g_gil_err = "gil_run_batch: device allocation failed (n_events)"; return GIL_ERR_HIP; } }
 #undef UPL
 #undef OUTB
-    const size_t lds = ((size_t)2 * L + ((tlen + 2) & ~1) + ncap + (ncap & 1) + 8 + NT + 8) * sizeof(double) +
-                       ((size_t)2 * ncap + 16) * sizeof(int) + (size_t)((ncap + 15) & ~15) + (size_t)2 * ((L + 15) & ~15);
+    const size_t lds = ((size_t)2 * L + ((tlen + 2) & ~1) + ncap + (ncap & 1) + 8 + 5 * NT + 8) * sizeof(double) +
+                       ((size_t)3 * ncap + 16) * sizeof(int) + (size_t)((ncap + 15) & ~15) + (size_t)2 * ((L + 15) & ~15);
     if (lds > 160 * 1024) return bad("system does not fit the 160 KB of LDS");
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&gil_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (lds > 48 * 1024 && hipFuncSetAttribute(NT == 64 ? reinterpret_cast<const void *>(&gil_kernel<64>) : reinterpret_cast<const void *>(&gil_kernel<256>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         g_gil_err = "gil_run_batch: cannot raise the dynamic LDS limit"; return GIL_ERR_HIP;
     }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_gil_err = "hipEventCreate failed"; return GIL_ERR_HIP; }
     (void)hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(gil_kernel, dim3((unsigned)S), dim3(NT), lds, nullptr, a);
+    if (NT == 64) hipLaunchKernelGGL(gil_kernel<64>, dim3((unsigned)S), dim3(64), lds, nullptr, a);
+    else hipLaunchKernelGGL(gil_kernel<256>, dim3((unsigned)S), dim3(256), lds, nullptr, a);
     (void)hipEventRecord(e1, nullptr);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipDeviceSynchronize();
