@@ -106,6 +106,7 @@ def load():
         "aps_method": (C.c_int, [vp]),
         "aps_mark_reference": (C.c_int, [vp, i32]),
         "aps_observe_scalars": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
+        "aps_observe_scalars_all": (C.c_int, [vp, i32, vp, vp, vp]),
         "aps_event_overhead": (C.c_int, [vp, i32, P(dbl)]),
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
@@ -261,6 +262,15 @@ class Handle:
             raise ValueError("block_table must have (K+1)*(K+1) entries")
         self._ck(self.lib.aps_observe_scalars(self._h, ensemble, int(x_wall), int(range_lo), int(range_hi), _ptr(tab), _ptr(out)))
         return {k: int(v) for k, v in zip(self.SCALARS, out)}
+
+    def observe_scalars_all(self, x_wall=0, ranges=None, block_table=None):
+        """observe_scalars for every ensemble of the handle in one pass; `ranges` = [E][2] (lo, hi) per ensemble.
+        Returns a list of dicts."""
+        out = np.zeros((self.E, len(self.SCALARS)), np.int64)
+        tab = None if block_table is None else np.ascontiguousarray(block_table, dtype=np.uint8)
+        rng = None if ranges is None else np.ascontiguousarray(ranges, dtype=np.int32).reshape(self.E, 2)
+        self._ck(self.lib.aps_observe_scalars_all(self._h, int(x_wall), _ptr(rng), _ptr(tab), _ptr(out)))
+        return [{k: int(v) for k, v in zip(self.SCALARS, row)} for row in out]
 
     # -- observation
     def observe(self, ensemble=0, want_field=True):

@@ -1019,22 +1019,24 @@ __global__ __launch_bounds__(NTHREADS) void field_sites(const FieldArgs a, const
 // (compute_v_eff_and_window, compute_blocking_probability, compute_mean_magnetizatoin, compute_D_eff_active,
 // PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py:123-229, :316-319, :500-525), taken on the device so that a sweep
 // needs no M x L density arrays.  All outputs are exact integers; the float formulas stay on the host.
-struct ScalarArgs {
-    const uint32_t *src, *orig, *occ_site;   // occ_site may be null (all-pairs formulation): occupancy from counts array
-    const uint32_t *ref;                     // [Npad] packed reference state by slot, or null
+struct ScalarArgs {                          // blockIdx.y = ensemble index within the call (arrays are strided by it)
+    const uint32_t *src;                     // [n][Npad]
+    const uint32_t *ref;                     // [n][Npad] packed reference state by slot, or null
+    const uint8_t *ref_ok;                   // [n] reference marked for this ensemble (null: all, if ref)
     const uint8_t *block_table;              // [(K+1)*(K+1)]: is a right neighbour holding (plus, minus) particles "blocking"?
-    const uint32_t *cnt_pm;                  // [L] per-site counts plus | minus << 16 (built by count_sites)
-    long long *out;                          // [16]
+    uint32_t *cnt_pm;                        // [n][L] per-site counts plus | minus << 16 (built by count_sites)
+    long long *out;                          // [n][16]
+    const int *lo_hi;                        // [n][2] site range of the range count, or null (lo, hi below)
     int Npad, L, K, x_wall, lo, hi;
 };
 enum { SC_N = 0, SC_SPIN, SC_POS, SC_WALL, SC_MAXPOS, SC_RANGE, SC_ATTEMPT, SC_BLOCKED, SC_DISP, SC_DISP2, SC_NDISP, SC_COUNT };
 
-__global__ __launch_bounds__(256) void count_sites(const uint32_t *__restrict__ src, uint32_t *cnt_pm, int Npad) {
+__global__ __launch_bounds__(256) void count_sites(const uint32_t *__restrict__ src, uint32_t *cnt_pm, int Npad, int L) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Npad) return;
-    const uint32_t w = src[i];
+    const uint32_t w = src[(size_t)blockIdx.y * Npad + i];
     if (w & DEAD_BIT) return;
-    atomicAdd(&cnt_pm[w & POS_MASK], (w & SPIN_BIT) ? 1u : 65536u);
+    atomicAdd(&cnt_pm[(size_t)blockIdx.y * L + (w & POS_MASK)], (w & SPIN_BIT) ? 1u : 65536u);
 }
 
 __device__ inline long long wave_sum(long long v) {
@@ -1045,22 +1047,27 @@ __device__ inline long long wave_sum(long long v) {
 
 __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
     long long v[SC_COUNT] = {0, 0, 0, 0, -1, 0, 0, 0, 0, 0, 0};
+    const int en = blockIdx.y;
+    const uint32_t *src = a.src + (size_t)en * a.Npad, *cnt_pm = a.cnt_pm + (size_t)en * a.L;
+    const uint32_t *ref = (a.ref && (!a.ref_ok || a.ref_ok[en])) ? a.ref + (size_t)en * a.Npad : nullptr;
+    const int lo = a.lo_hi ? a.lo_hi[2 * en] : a.lo, hi = a.lo_hi ? a.lo_hi[2 * en + 1] : a.hi;
+    long long *out = a.out + (size_t)en * 16;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.Npad; i += gridDim.x * blockDim.x) {
-        const uint32_t w = a.src[i];
+        const uint32_t w = src[i];
         if (w & DEAD_BIT) continue;
         const int p = (int)(w & POS_MASK);
         const bool plus = (w & SPIN_BIT) != 0;
         v[SC_N] += 1; v[SC_SPIN] += plus ? 1 : -1; v[SC_POS] += p;
         v[SC_WALL] += p >= a.x_wall;
         v[SC_MAXPOS] = max(v[SC_MAXPOS], (long long)p);
-        v[SC_RANGE] += (p >= a.lo && p <= a.hi);
+        v[SC_RANGE] += (p >= lo && p <= hi);
         if (plus && p < a.L - 1) {                            // ref :197-229: movers on sites 0..L-2, blocked by the right neighbour
-            const uint32_t c = a.cnt_pm[p + 1];
+            const uint32_t c = cnt_pm[p + 1];
             v[SC_ATTEMPT] += 1;
             v[SC_BLOCKED] += a.block_table[(c & 0xFFFFu) * (a.K + 1) + (c >> 16)];
         }
-        if (a.ref) {
-            const uint32_t r = a.ref[i];
+        if (ref) {
+            const uint32_t r = ref[i];
             if (!(r & DEAD_BIT)) { const long long d = (long long)p - (long long)(r & POS_MASK); v[SC_DISP] += d; v[SC_DISP2] += d * d; v[SC_NDISP] += 1; }
         }
     }
@@ -1070,10 +1077,10 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
             long long m = v[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-            if ((threadIdx.x & 63) == 0) atomicMax(&a.out[k], m);
+            if ((threadIdx.x & 63) == 0) atomicMax(&out[k], m);
         } else {
             const long long s = wave_sum(v[k]);
-            if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(&a.out[k]), (unsigned long long)s);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(&out[k]), (unsigned long long)s);
         }
     }
 }
@@ -1130,7 +1137,7 @@ struct aps_handle {
     hipGraphExec_t gexec = nullptr;
     int graph_steps = 0;
     uint32_t *d_ref = nullptr, *d_cnt_pm = nullptr;   // observables: reference state per slot [E][Npad], per-site counts [L]
-    uint8_t *d_block_table = nullptr; long long *d_scal = nullptr;
+    uint8_t *d_block_table = nullptr, *d_ref_ok = nullptr; long long *d_scal = nullptr; int *d_lo_hi = nullptr;
     std::vector<char> ref_set;                         // per ensemble: reference marked (and slot order unchanged since)
     // per-kernel timing (aps_step_timed / aps_step_profile): an event before every launch, kind of that launch
     bool profiling = false;
@@ -1622,7 +1629,7 @@ void aps_destroy(aps_handle *h) {
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_lo_hi, (void *)h->d_ref_ok, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
                     h->d_nexit, h->d_tmp_sp8, h->d_tmp_tinfo};
@@ -1884,36 +1891,61 @@ int aps_mark_reference(aps_handle *h, int32_t e) {
     return APS_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// scalar sums of ensembles [e0, e0 + n): one counting launch, one summing launch, one download
+int observe_scalars_impl(aps_handle *h, int e0, int n, int32_t x_wall, const int32_t *lo_hi, int32_t lo, int32_t hi,
+                         const uint8_t *block_table, int64_t *out11) {
+    const int K = h->p.K, L = h->p.L;
+    int rc;
+    if (!h->d_scal && ((rc = dev_alloc(h, &h->d_scal, (size_t)16 * h->E)) || (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L * h->E)) ||
+                       (rc = dev_alloc(h, &h->d_block_table, (size_t)(K + 1) * (K + 1))) || (rc = dev_alloc(h, &h->d_lo_hi, (size_t)2 * h->E)) ||
+                       (rc = dev_alloc(h, &h->d_ref_ok, (size_t)h->E)))) return rc;
+    std::vector<uint8_t> table((size_t)(K + 1) * (K + 1), 0);
+    if (block_table) table.assign(block_table, block_table + table.size());
+    else for (int cp = 0; cp <= K; ++cp) for (int cm = 0; cm <= K; ++cm) table[(size_t)cp * (K + 1) + cm] = cp + cm >= 1;
+    std::vector<long long> init((size_t)16 * n, 0);
+    for (int k = 0; k < n; ++k) init[(size_t)16 * k + SC_MAXPOS] = -1;
+    std::vector<uint8_t> ok((size_t)n, 0);
+    for (int k = 0; k < n; ++k) ok[(size_t)k] = (!h->ref_set.empty() && h->ref_set[(size_t)(e0 + k)]) ? 1 : 0;
+    HIP_TRY(h, hipMemcpyAsync(h->d_block_table, table.data(), table.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_scal, init.data(), init.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ref_ok, ok.data(), ok.size(), hipMemcpyHostToDevice, h->stream));
+    if (lo_hi) HIP_TRY(h, hipMemcpyAsync(h->d_lo_hi, lo_hi, (size_t)2 * n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_cnt_pm, 0, (size_t)L * n * 4, h->stream));
+    const uint32_t *src = h->d_src + (size_t)e0 * h->Npad;
+    hipLaunchKernelGGL(count_sites, dim3((unsigned)(h->Npad / 256), (unsigned)n), dim3(256), 0, h->stream, src, h->d_cnt_pm, (int)h->Npad, L);
+    ScalarArgs a{};
+    a.src = src; a.block_table = h->d_block_table; a.cnt_pm = h->d_cnt_pm; a.out = h->d_scal;
+    a.ref = h->d_ref ? h->d_ref + (size_t)e0 * h->Npad : nullptr; a.ref_ok = h->d_ref_ok;
+    a.lo_hi = lo_hi ? h->d_lo_hi : nullptr;
+    a.Npad = (int)h->Npad; a.L = L; a.K = K; a.x_wall = x_wall; a.lo = lo; a.hi = hi;
+    hipLaunchKernelGGL(observe_scalars, dim3((unsigned)std::min<int64_t>(h->Npad / 256, 512), (unsigned)n), dim3(256), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<long long> res((size_t)16 * n);
+    HIP_TRY(h, hipMemcpyAsync(res.data(), h->d_scal, res.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) for (int q = 0; q < SC_COUNT; ++q) out11[(size_t)k * SC_COUNT + q] = res[(size_t)16 * k + q];
+    return APS_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int aps_observe_scalars(aps_handle *h, int32_t e, int32_t x_wall, int32_t range_lo, int32_t range_hi, const uint8_t *block_table,
                         int64_t *out11) {
     if (!h) return APS_ERR_ARG;
     if (e < 0 || e >= h->E || !out11) return fail(h, APS_ERR_ARG, "aps_observe_scalars: bad argument");
     if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_observe_scalars: no state uploaded for this ensemble");
-    const int K = h->p.K, L = h->p.L;
-    int rc;
-    if (!h->d_scal && ((rc = dev_alloc(h, &h->d_scal, 16)) || (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L)) ||
-                       (rc = dev_alloc(h, &h->d_block_table, (size_t)(K + 1) * (K + 1))))) return rc;
-    std::vector<uint8_t> table((size_t)(K + 1) * (K + 1), 0);
-    if (block_table) table.assign(block_table, block_table + table.size());
-    else for (int cp = 0; cp <= K; ++cp) for (int cm = 0; cm <= K; ++cm) table[(size_t)cp * (K + 1) + cm] = cp + cm >= 1;
-    long long init[16] = {0};
-    init[SC_MAXPOS] = -1;
-    HIP_TRY(h, hipMemcpyAsync(h->d_block_table, table.data(), table.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_scal, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_cnt_pm, 0, (size_t)L * 4, h->stream));
-    const uint32_t *src = h->d_src + (size_t)e * h->Npad;
-    hipLaunchKernelGGL(count_sites, dim3((unsigned)(h->Npad / 256)), dim3(256), 0, h->stream, src, h->d_cnt_pm, (int)h->Npad);
-    ScalarArgs a{};
-    a.src = src; a.orig = h->d_orig + (size_t)e * h->Npad; a.block_table = h->d_block_table; a.cnt_pm = h->d_cnt_pm; a.out = h->d_scal;
-    a.ref = (h->d_ref && !h->ref_set.empty() && h->ref_set[(size_t)e]) ? h->d_ref + (size_t)e * h->Npad : nullptr;
-    a.Npad = (int)h->Npad; a.L = L; a.K = K; a.x_wall = x_wall; a.lo = range_lo; a.hi = range_hi;
-    hipLaunchKernelGGL(observe_scalars, dim3((unsigned)std::min<int64_t>(h->Npad / 256, 512)), dim3(256), 0, h->stream, a);
-    HIP_TRY(h, hipGetLastError());
-    long long res[16];
-    HIP_TRY(h, hipMemcpyAsync(res, h->d_scal, sizeof(res), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (int k = 0; k < SC_COUNT; ++k) out11[k] = res[k];
-    return APS_OK;
+    return observe_scalars_impl(h, e, 1, x_wall, nullptr, range_lo, range_hi, block_table, out11);
+}
+
+int aps_observe_scalars_all(aps_handle *h, int32_t x_wall, const int32_t *range_lo_hi, const uint8_t *block_table, int64_t *out11) {
+    if (!h) return APS_ERR_ARG;
+    if (!out11) return fail(h, APS_ERR_ARG, "aps_observe_scalars_all: bad argument");
+    if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_observe_scalars_all: upload a state for every ensemble first");
+    return observe_scalars_impl(h, 0, h->E, x_wall, range_lo_hi, 0, -1, block_table, out11);
 }
 
 int aps_method(aps_handle *h) { return h ? h->method : APS_ERR_ARG; }

@@ -431,16 +431,28 @@ def run_batched_statistics(systems, T=10.0, obs_dt=0.01):
             if want > done:
                 h.step(want - done)
                 done = want
-            for e, acc in enumerate(accs):
-                if k == acc.start:
+            if k == accs[0].start:
+                for e in range(len(accs)):
                     h.mark_reference(ensemble=e)
-                n_live = len(inits[e][0])                            # no exits: the particle number is constant
-                sums = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, block_table=acc.block_table(n_live))
-                n_front = None
-                if k >= acc.start and sums["max_pos"] >= 0:
-                    lo, hi = acc.front_range(sums["max_pos"])
-                    n_front = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, range_lo=lo, range_hi=hi)["n_range"]
-                acc.add(k, sums, n_front)
+            # all ensembles in one pass; the blocking threshold is shared when the particle numbers allow it
+            tables = [acc.block_table(len(inits[e][0])) for e, acc in enumerate(accs)]   # no exits: particle numbers are constant
+            if all(np.array_equal(tb, tables[0]) for tb in tables[1:]):
+                rows = h.observe_scalars_all(x_wall=accs[0].x_wall, block_table=tables[0])
+                fronts = [None] * len(accs)
+                if k >= accs[0].start:
+                    ranges = [accs[e].front_range(r["max_pos"]) if r["max_pos"] >= 0 else (0, -1) for e, r in enumerate(rows)]
+                    again = h.observe_scalars_all(x_wall=accs[0].x_wall, ranges=ranges, block_table=tables[0])
+                    fronts = [again[e]["n_range"] if rows[e]["max_pos"] >= 0 else None for e in range(len(accs))]
+                for e, acc in enumerate(accs):
+                    acc.add(k, rows[e], fronts[e])
+            else:
+                for e, acc in enumerate(accs):
+                    sums = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, block_table=tables[e])
+                    n_front = None
+                    if k >= acc.start and sums["max_pos"] >= 0:
+                        lo, hi = acc.front_range(sums["max_pos"])
+                        n_front = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, range_lo=lo, range_hi=hi)["n_range"]
+                    acc.add(k, sums, n_front)
         for ps in systems:
             ps.steps_done = done
     finally:

@@ -136,6 +136,11 @@ int aps_mark_reference(aps_handle *h, int32_t ensemble);
 int aps_observe_scalars(aps_handle *h, int32_t ensemble, int32_t x_wall, int32_t range_lo, int32_t range_hi,
                         const uint8_t *block_table, int64_t *out11);
 
+/* The same for ALL ensembles of the handle in one pass (two launches, one download): out11 is [n_ensembles][11];
+ * range_lo_hi [n_ensembles][2] gives each ensemble's own site range (NULL: empty range). */
+int aps_observe_scalars_all(aps_handle *h, int32_t x_wall, const int32_t *range_lo_hi, const uint8_t *block_table,
+                            int64_t *out11);
+
 /* m-field for a caller-supplied histogram: compute_local_m_field(counts_p, counts_m) (ref :216-246) */
 int aps_field_from_counts(aps_handle *h, int32_t ensemble, const int64_t *counts_p, const int64_t *counts_m,
                           double *m_field);
