@@ -156,4 +156,41 @@ inline void weight_table(double sigma_grid, int L_, int K, bool periodic, std::v
 }
 
 
+// value of the lane n below within the same row of 16 lanes (0.0 when that lane is outside the row): two 32-bit DPP moves
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x110 | N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x110 | N, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// inclusive scan over one wavefront without touching LDS: Hillis-Steele inside the rows of 16 lanes (DPP), then the three
+// row totals are added to the rows above them
+__device__ __forceinline__ double wave_scan_inclusive(double v) {
+    v += row_shr<1>(v); v += row_shr<2>(v); v += row_shr<4>(v); v += row_shr<8>(v);
+    const int row = (threadIdx.x & 63) >> 4;
+    const double t0 = read_lane(v, 15), t1 = read_lane(v, 31), t2 = read_lane(v, 47);
+    double add = 0.0;
+    if (row > 0) add = t0;
+    if (row > 1) add += t1;
+    if (row > 2) add += t2;
+    return v + add;
+}
+
+// weight of source site p seen from site x, images folded in (same lookups as the stepper's field kernels)
+__device__ inline double site_weight(const Model &M, const double *tab, int tlen, int x, int p) {
+    const int L = M.L;
+    int d = x > p ? x - p : p - x;
+    if (M.periodic) { d = min(d, L - d); return tab[min(d, tlen)]; }
+    const int s = x + p + 1;
+    return tab[min(d, tlen)] + tab[min(min(s, 2 * L - s), tlen)];
+}
+
 }  // namespace

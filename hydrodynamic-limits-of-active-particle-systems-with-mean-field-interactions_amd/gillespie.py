@@ -35,6 +35,9 @@ def _lib():
         lib.gil_last_error.restype, lib.gil_last_error.argtypes = C.c_char_p, []
         lib.gil_run_batch.restype = C.c_int
         lib.gil_run_batch.argtypes = [C.POINTER(GilParams)] + [C.c_void_p] * 14 + [C.POINTER(C.c_double)]
+        lib.gil_large_last_error.restype, lib.gil_large_last_error.argtypes = C.c_char_p, []
+        lib.gil_run_large.restype = C.c_int
+        lib.gil_run_large.argtypes = [C.POINTER(GilParams), C.c_int32] + [C.c_void_p] * 12 + [C.POINTER(C.c_double)]
         lib._gil_ready = True
     return lib
 
@@ -188,3 +191,42 @@ def run_batched_exact_statistics(systems, T=10.0, obs_dt=0.01):
         ps.n_events = int(r["n_events"][s])
     first.kernel_ms = r["kernel_ms"]
     return rows
+
+
+def run_large_raw(*, L, K, periodic, sigma_grid, rate_diffusion, rate_active, beta, state, times_obs, T, seed=0,
+                  minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False, k_on=0.0, k_off=0.0, k_exit=0.0,
+                  anchor_mask=None, uniforms=None, max_events=None, want_states=True, device=0):
+    """One large system (gil_run_large): state = (pos, sigma[, bound]).  Returns a dict like run_raw's, without a system axis."""
+    lib = _lib()
+    pos0 = np.ascontiguousarray(state[0], dtype=np.int32)
+    sg0 = np.ascontiguousarray(state[1], dtype=np.int8)
+    bd0 = None if len(state) < 3 or state[2] is None else np.ascontiguousarray(state[2], dtype=np.uint8)
+    n0 = len(pos0)
+    times = np.ascontiguousarray(times_obs, dtype=np.float64)
+    M = len(times)
+    if uniforms is not None:
+        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+        max_events = uniforms.shape[0]
+    elif max_events is None:
+        max_events = 2 ** 40
+    betas = np.array([float(beta)])
+    mask = None if anchor_mask is None or not np.any(anchor_mask) else np.ascontiguousarray(anchor_mask, dtype=np.uint8)
+    par = GilParams(L=L, K=K, periodic=int(bool(periodic)), minus_anchor=int(bool(minus_anchor)), immobilize=int(bool(immobilize)),
+                    suppress_flip=int(bool(suppress_flip)), crowding=int(bool(crowding)), n_systems=1, n_cap=max(n0, 1), n_obs=M,
+                    device=device, x_wall=0, ref_obs=-1, sigma_grid=float(sigma_grid), rate_diffusion=float(rate_diffusion),
+                    rate_active=float(rate_active), k_on=float(k_on), k_off=float(k_off), k_exit=float(k_exit), T=float(T),
+                    seed=int(seed) & (2 ** 64 - 1), max_events=int(max_events), beta=_p(betas).value,
+                    anchor_mask=None if mask is None else _p(mask).value, times_obs=_p(times).value, front_lo=None, block_table=None)
+    ncap = max(n0, 1)
+    pos_obs = np.zeros((M, ncap), np.int32) if want_states else None
+    sg_obs = np.zeros((M, ncap), np.int8) if want_states else None
+    fl_obs = np.zeros((M, ncap), np.uint8) if want_states else None
+    n_rec, n_ev, t_fin, n_exit = np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1), np.zeros(1, np.int32)
+    exits = np.zeros((ncap, 3))
+    ms = C.c_double()
+    rc = lib.gil_run_large(C.byref(par), n0, _p(pos0), _p(sg0), _p(bd0), _p(uniforms), _p(pos_obs), _p(sg_obs), _p(fl_obs), _p(n_rec),
+                           _p(n_ev), _p(t_fin), _p(exits), _p(n_exit), C.byref(ms))
+    if rc != 0:
+        raise capi.ApsError(rc, lib.gil_large_last_error().decode())
+    return dict(pos=pos_obs, sigma=sg_obs, flags=fl_obs, n_recorded=int(n_rec[0]), n_events=int(n_ev[0]), t_final=float(t_fin[0]),
+                exits=exits, n_exits=int(n_exit[0]), n0=n0, kernel_ms=ms.value)

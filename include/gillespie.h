@@ -62,6 +62,16 @@ int gil_run_batch(const gil_params *p, const int32_t *n0, const int32_t *pos0, c
                   int32_t *n_recorded, int64_t *n_events, double *t_final, double *exits, int32_t *n_exits,
                   double *kernel_ms);
 
+/* The same loop for ONE system too large for a workgroup's LDS (n_systems must be 1; L <= 2^25, L*K <= 2^27,
+ * n_cap <= 2^20): the BASELINE size N = 1e5, where the reference recomputes the whole field and all N rates before
+ * every event (PARTICLE_solver_CLASS.py:512-513; 0.8 events/s measured).  One persistent workgroup of 1024 threads,
+ * state in global memory, a site -> particle map and two-level rate sums so that an event touches only what it
+ * changes.  Arguments as in gil_run_batch for a single system (no scalar sums); uniforms [max_events][4] optional. */
+int gil_run_large(const gil_params *p, int32_t n0, const int32_t *pos0, const int8_t *sigma0, const uint8_t *bound0,
+                  const double *uniforms, int32_t *pos_obs, int8_t *sigma_obs, uint8_t *flags_obs, int32_t *n_recorded,
+                  int64_t *n_events, double *t_final, double *exits, int32_t *n_exits, double *kernel_ms);
+const char *gil_large_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

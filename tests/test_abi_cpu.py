@@ -116,7 +116,7 @@ def test_gillespie_header_symbols_exported_and_struct_layout():
     with open(os.path.join(os.path.dirname(capi.HEADER_PATH), "gillespie.h")) as fh:
         text = fh.read()
     names = sorted(set(re.findall(r"\b(gil_[a-z_0-9]+)\s*\(", text)))
-    assert names == ["gil_last_error", "gil_run_batch"]
+    assert names == ["gil_large_last_error", "gil_last_error", "gil_run_batch", "gil_run_large"]
     for n in names:
         assert hasattr(lib, n), n
     body = re.search(r"typedef struct gil_params \{(.*?)\} gil_params;", text, re.S).group(1)

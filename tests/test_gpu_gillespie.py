@@ -206,3 +206,56 @@ def test_exact_sweep_statistics_from_device_sums_equal_full_outputs():
     for key in ("means", "stds", "ses", "D_means", "D_ses", "m_means", "m_stds", "m_ses", "rho_means", "rho_ses", "block_means", "block_ses"):
         np.testing.assert_allclose(slim[key], full[key], rtol=1e-8, atol=1e-11, err_msg=key)
     assert np.all(np.isfinite(full["means"])) and np.all(full["block_means"] >= 0.0)
+
+
+BIG_CASES = [
+    dict(tag="big_reflect_k1", L=3000, N=1500, site_capacity=1, local_kernel_sigma=0.01, rate_diffusion=0.5, rate_active=4.0, beta=1.1),
+    dict(tag="big_periodic_k2", L=2000, N=2600, site_capacity=2, local_kernel_sigma=0.02, periodic=True, rate_diffusion=0.8, rate_active=3.0, beta=0.6),
+    dict(tag="big_global_field", L=1500, N=900, site_capacity=1, local_kernel_sigma=0.0, rate_diffusion=1.0, rate_active=2.0, beta=1.5),
+    dict(tag="big_anchors_exit", L=2400, N=1700, site_capacity=2, local_kernel_sigma=0.01, rate_diffusion=0.6, rate_active=4.0, beta=0.9,
+         anchor_positions=[0.3, 0.7], anchor_radius=0.05, k_on=3.0, k_off=1.0, k_exit=2.0),
+]
+
+
+@pytest.mark.parametrize("case", BIG_CASES, ids=lambda c: c["tag"])
+def test_large_system_kernel_same_uniforms_same_trajectory(gil, case):
+    """gil_run_large (state in global memory, site map, two-level rate sums) against the oracle with the same uniforms."""
+    case = dict(case)
+    tag, N = case.pop("tag"), case.pop("N")
+    kw = dict(xlim=1.0, scale_rates=False, k_on=0.0, k_off=0.0, k_exit=0.0)
+    kw.update(case)
+    T, obs_dt, n_events = 0.3, 0.02, 8000
+    table = np.random.default_rng(zlib.crc32(tag.encode())).random((n_events, 4))
+    orc = GillespieOracle(init="fixed", N=N, rng=np.random.default_rng(5), **kw)
+    pos0, sigma0 = orc.init_particles()
+    orc.rng = TableRng(table)
+    L = kw["L"]
+    pos, sigma, bound = pos0.copy(), sigma0.copy(), np.zeros(N, bool)
+    cp, cm = np.bincount(pos[sigma == 1], minlength=L), np.bincount(pos[sigma == -1], minlength=L)
+    times = np.arange(0.0, T, obs_dt)
+    snaps, exits, k, t, ev = [(pos.copy(), sigma.copy(), bound.copy())], ([], []), 1, 0.0, 0
+    while t < T and k < len(times) and ev < n_events:
+        field = orc.mean_field(cp, cm)
+        pos, sigma, bound, tau = orc.fire_event(pos, sigma, bound, field, cp, cm, t, exits)
+        ev += 1
+        t += tau
+        if t > T:
+            break
+        while k < len(times) and times[k] <= t:
+            snaps.append((pos.copy(), sigma.copy(), bound.copy()))
+            k += 1
+    P = orc.par
+    r = gil.run_large_raw(L=L, K=P.K, periodic=P.periodic, sigma_grid=P.sigma_grid if P.sigma_kernel > 0 else 0.0,
+                          rate_diffusion=P.rate_diffusion, rate_active=P.rate_active, beta=P.beta, state=(pos0, sigma0), times_obs=times,
+                          T=T, minus_anchor=P.minus_anchor, immobilize=P.immobilize_when_anchored, suppress_flip=P.suppress_flip_when_bound,
+                          crowding=P.crowding_suppresses_rates, k_on=P.k_on, k_off=P.k_off, k_exit=P.k_exit, anchor_mask=P.is_anchor_site,
+                          uniforms=table)
+    assert r["n_events"] == ev and r["n_recorded"] == len(snaps), (tag, r["n_events"], ev)
+    np.testing.assert_allclose(r["t_final"], t, rtol=1e-12)
+    for kk, (p, s, b) in enumerate(snaps):
+        live = (r["flags"][kk, :N] & 2) != 0
+        assert np.array_equal(r["pos"][kk, :N][live], p), (tag, kk)
+        assert np.array_equal(r["sigma"][kk, :N][live], s) and np.array_equal((r["flags"][kk, :N][live] & 1).astype(bool), b), (tag, kk)
+    assert r["n_exits"] == len(exits[0])
+    assert np.array_equal(r["exits"][:r["n_exits"], 1].astype(int), np.array(exits[1], dtype=int))
+    assert ev > 300, (tag, ev)
