@@ -79,6 +79,17 @@ __device__ inline double big_rate(const BigArgs &a, const double *tab, int i, lo
                     a.occ[p], l >= 0 ? a.occ[l] : 0, r < L ? a.occ[r] : 0).total;
 }
 
+// lowest / highest thread of the workgroup for which `flag` holds, into *lo / *hi: one LDS atomic per wavefront
+// (hundreds of same-address atomics from single lanes serialise at ~25 cycles each)
+__device__ inline void note_first_last(bool flag, int *lo, int *hi) {
+    const unsigned long long m = __ballot(flag);
+    if (m && (threadIdx.x & 63) == 0) {
+        const int base = (int)(threadIdx.x & ~63u);
+        atomicMin(lo, base + __builtin_ctzll(m));
+        atomicMax(hi, base + 63 - __builtin_clzll(m));
+    }
+}
+
 // inclusive scan over the 1024 threads; `xw` = BW doubles of LDS
 __device__ inline double block_scan_inclusive(double v, double *xw) {
     double inc = wave_scan_inclusive(v);
@@ -159,6 +170,12 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
     k_obs = 1;
     bool have_event = false, dirty_all = false;
     int ev_a = 0, ev_b = 0;
+#ifdef APS_STAMPS
+    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s0 = __builtin_amdgcn_s_memtime();
+#define BSTAMP(k) { const unsigned long long s1_ = __builtin_amdgcn_s_memtime(); st[k] += s1_ - s0; s0 = s1_; }
+#else
+#define BSTAMP(k)
+#endif
     const int reach = (M.field_mode ? a.tlen - 1 : 0) + 1;
     while (tnow < a.p.T && k_obs < nobs && n_ev < a.p.max_events) {
         // ---- A: re-evaluate the rates the previous event changed
@@ -173,23 +190,51 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
                 len = 2 * reach + 2;
                 if (len >= L || (!M.periodic && reach >= L)) { lo = 0; len = L; }
             }
+            auto append = [&](bool flag, int item) {           // one LDS atomic per wavefront: ballot + mbcnt compaction
+                const unsigned long long m = __ballot(flag);
+                if (!m) return;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[0], __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (flag) a.work[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = item;
+            };
             if (dirty_all) {
-                for (int i = t; i < N; i += BT) if (a.flg[i] & F_ALIVE) a.work[atomicAdd(&ctl[0], 1)] = i;
+                for (int i0 = 0; i0 < N; i0 += BT) {
+                    const int i = i0 + t;
+                    append(i < N && (a.flg[i] & F_ALIVE), i);
+                }
             } else {
-                for (int k = t; k < len; k += BT) {            // sites in reach -> their particles, through the map
-                    int x = lo + k;
-                    if (M.periodic) { x %= L; if (x < 0) x += L; }
-                    else if (x < 0 || x >= L) continue;
-                    const int n = a.occ[x];
-                    for (int q = 0; q < n; ++q) a.work[atomicAdd(&ctl[0], 1)] = a.slot[(size_t)x * K + q];
+                constexpr int U = 4;                           // site iterations whose occupancy loads are in flight together
+                for (int k0 = 0; k0 < len; k0 += U * BT) {     // sites in reach -> their particles, through the map
+                    int xs[U], ns[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int k = k0 + u * BT + t;
+                        int x = lo + k;
+                        if (M.periodic) { x %= L; if (x < 0) x += L; }
+                        const bool in = k < len && x >= 0 && x < L;
+                        xs[u] = in ? x : 0;
+                        ns[u] = in ? a.occ[x] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        for (int q = 0; __ballot(q < ns[u]); ++q) append(q < ns[u], q < ns[u] ? a.slot[(size_t)xs[u] * K + q] : 0);
                 }
             }
             __syncthreads();
+            BSTAMP(0)
             const int nwork = ctl[0];
-            for (int j = t; j < nwork; j += BT) {
-                const int i = a.work[j];
-                a.rate[i] = big_rate(a, tab, i, gsum_s, gsum_n);
-                if (atomicExch(&bflag[i / PB], 1) == 0) blist[atomicAdd(&ctl[1], 1)] = i / PB;
+            for (int base = 0; base < nwork; base += 4 * BT) {   // the list entries of four items per thread are fetched together
+                int is[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int j = base + u * BT + t; is[u] = j < nwork ? a.work[j] : -1; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = is[u];
+                    if (i < 0) continue;
+                    a.rate[i] = big_rate(a, tab, i, gsum_s, gsum_n);
+                    if (atomicExch(&bflag[i / PB], 1) == 0) blist[atomicAdd(&ctl[1], 1)] = i / PB;
+                }
             }
             __syncthreads();
             const int nb_dirty = ctl[1];
@@ -202,10 +247,12 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
             }
             __syncthreads();
         }
+        BSTAMP(1)
         // ---- B: total rate, draws, choice of the block and of the particle
         double mine = 0.0;
         for (int j = t * a.cb; j < min(a.nblk, (t + 1) * a.cb); ++j) mine += a.bsum[j];
         const double inc = block_scan_inclusive(mine, xw);
+        BSTAMP(5)
         if (t == BT - 1) dsel[0] = inc;
         if ((n_ev - ev_base) >= BT || n_ev == 0) {
             ev_base = n_ev;
@@ -226,15 +273,17 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
             }
             draws[4 * t] = -log1p(-u0); draws[4 * t + 1] = u1; draws[4 * t + 2] = u2; draws[4 * t + 3] = u3;
         }
-        if (t == 0) { ctl[2] = BT; ctl[3] = -1; ctl[4] = PB; ctl[5] = -1; }
+        if (t == 0) { ctl[2] = BT; ctl[3] = -1; ctl[4] = PB; ctl[5] = -1; ctl[13] = -1; ctl[14] = BT; ctl[15] = -1; ctl[16] = BT; }
         __syncthreads();
+        BSTAMP(6)
         const double R = dsel[0];
         if (!(R > 0.0)) { tnow = INFINITY; break; }           // ref :355
         const double *dr = draws + 4 * (int)(n_ev - ev_base);
         const double tau = (1.0 / R) * dr[0], target = dr[1] * R, u2 = dr[2], u3 = dr[3];
-        if (inc > target && mine > 0.0) atomicMin(&ctl[2], t);
-        if (mine > 0.0) atomicMax(&ctl[3], t);
+        note_first_last(inc > target && mine > 0.0, &ctl[2], &ctl[13]);
+        note_first_last(mine > 0.0, &ctl[14], &ctl[3]);
         __syncthreads();
+        BSTAMP(7)
         const int tsel = ctl[2] < BT ? ctl[2] : ctl[3];        // target rounded past the total: last thread with any rate
         if (t == tsel) {                                       // which of this thread's blocks
             double run = inc - mine;
@@ -247,16 +296,19 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
             ctl[6] = jsel; dsel[1] = before;
         }
         __syncthreads();
+        BSTAMP(8)
         const int jsel = ctl[6];
         {                                                      // the particle inside the block: its first 256 threads scan it
             double r = 0.0;
             const int i = jsel * PB + t;
             if (t < PB && i < N) r = a.rate[i];
             const double binc = block_scan_inclusive(r, xw) + dsel[1];
-            if (t < PB && r > 0.0) { if (binc > target) atomicMin(&ctl[4], t); atomicMax(&ctl[5], t); }
+            note_first_last(t < PB && r > 0.0 && binc > target, &ctl[4], &ctl[15]);
+            note_first_last(t < PB && r > 0.0, &ctl[16], &ctl[5]);
             __syncthreads();
         }
         const int isel = jsel * PB + (ctl[4] < PB ? ctl[4] : ctl[5]);
+        BSTAMP(2)
         // ---- C: one thread applies the event (ref :363-446) and keeps the site map
         if (t == 0) {
             const int i = isel, p = a.pos[i];
@@ -317,6 +369,7 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
         __syncthreads();
         const int kind = ctl[8], p_old = ctl[9], p_new = ctl[10], sg = ctl[11];
         if (kind == 3) n_exit += 1;
+        BSTAMP(3)
         // ---- D: the event's change of the smoothed histograms
         if (!M.field_mode) {
             if (kind == 2) gsum_s -= 2 * sg;
@@ -327,18 +380,32 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
             const bool wrap1 = kind == 1 && M.periodic && (p_old - p_new > 1 || p_new - p_old > 1);
             int lo = centre - Rt, len = 2 * Rt + 1 + span;
             if (wrap1 || len >= L || (!M.periodic && Rt >= L)) { lo = 0; len = L; }
-            for (int k = t; k < len; k += BT) {
-                int x = lo + k;
-                if (M.periodic) { x %= L; if (x < 0) x += L; }
-                else if (x < 0 || x >= L) continue;
-                const double g0 = site_weight(M, tab, a.tlen, x, p_old);
-                if (kind == 1) {
-                    const double g1 = site_weight(M, tab, a.tlen, x, p_new), d = g1 - g0;      // exact on the weight grid
-                    a.W[x] += d; a.S[x] += sg > 0 ? d : -d;
-                } else if (kind == 2) {
-                    a.S[x] -= sg > 0 ? 2.0 * g0 : -2.0 * g0;
-                } else {
-                    a.W[x] -= g0; a.S[x] -= sg > 0 ? g0 : -g0;
+            constexpr int U = 4;                               // sites per thread whose loads are in flight together
+            for (int k0 = 0; k0 < len; k0 += U * BT) {
+                int xs[U]; double ws[U], ss[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u * BT + t;
+                    int x = lo + k;
+                    if (M.periodic) { x %= L; if (x < 0) x += L; }
+                    const bool in = k < len && x >= 0 && x < L;
+                    xs[u] = in ? x : -1;
+                    ws[u] = in ? a.W[x] : 0.0; ss[u] = in ? a.S[x] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int x = xs[u];
+                    if (x >= 0) {
+                        const double g0 = site_weight(M, tab, a.tlen, x, p_old);
+                        if (kind == 1) {
+                            const double g1 = site_weight(M, tab, a.tlen, x, p_new), d = g1 - g0;  // exact on the weight grid
+                            a.W[x] = ws[u] + d; a.S[x] = ss[u] + (sg > 0 ? d : -d);
+                        } else if (kind == 2) {
+                            a.S[x] = ss[u] - (sg > 0 ? 2.0 * g0 : -2.0 * g0);
+                        } else {
+                            a.W[x] = ws[u] - g0; a.S[x] = ss[u] - (sg > 0 ? g0 : -g0);
+                        }
+                    }
                 }
             }
         }
@@ -352,6 +419,7 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
             if (lane == 63) a.bsum[j] = v;
         }
         __syncthreads();
+        BSTAMP(4)
         have_event = true;
         ev_a = p_old; ev_b = p_new;
         dirty_all = !M.field_mode && (kind == 2 || kind == 3);
@@ -361,6 +429,9 @@ __global__ __launch_bounds__(BT) void gil_big_kernel(const BigArgs a) {
         if (tnow > a.p.T) break;
         while (k_obs < nobs && t_next <= tnow) { record(k_obs); ++k_obs; t_next = k_obs < nobs ? a.times[k_obs] : INFINITY; }
     }
+#ifdef APS_STAMPS
+    if (t == 0 && a.exits) for (int k = 0; k < 12; ++k) a.exits[k] = (double)st[k];   // diagnostic build only
+#endif
     if (t == 0) {
         if (a.n_recorded) a.n_recorded[0] = k_obs;
         if (a.n_events) a.n_events[0] = n_ev;

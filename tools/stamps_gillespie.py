@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
 lib = "/tmp/libaps_stamps_gil.so"
-src = [os.path.join(ROOT, PKG, "csrc", f) for f in ("aps_hip.hip", "pde_hip.hip", "gillespie_hip.hip")]
+src = [os.path.join(ROOT, PKG, "csrc", f) for f in ("aps_hip.hip", "pde_hip.hip", "gillespie_hip.hip", "gillespie_big_hip.hip")]
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DAPS_STAMPS",
                 "-I", os.path.join(ROOT, "include"), "-o", lib] + src, check=True)
 capi = importlib.import_module(PKG + ".capi")
@@ -23,3 +23,15 @@ for nsys in (1, 1024):
     print(f"{nsys} system(s): kernel {r['kernel_ms']:.1f} ms, system 0: {ev} events, {r['kernel_ms'] * 1e3 / max(r['n_events'].max(), 1):.2f} us/event")
     for name, c in zip(("A rates+scan", "B draws+select", "C apply", "D field", "E time/obs"), st):
         print(f"   {name:16s} {c / ev:8.0f} cycles/event")
+
+# the large-system kernel at the BASELINE size
+L, N = 200_000, 100_000
+pos = np.sort(rng.choice(L, size=N, replace=False)).astype(np.int32)
+sg = rng.choice(np.array([1, -1], np.int8), size=N)
+r = gil.run_large_raw(L=L, K=1, periodic=False, sigma_grid=0.005 * L, rate_diffusion=0.02, rate_active=5.0, beta=0.7, state=(pos, sg),
+                      times_obs=np.array([0.0, 1e9]), T=1e9, seed=1, max_events=5000, want_states=False)
+ev = r["n_events"]
+print(f"large system N={N}: {ev} events, {r['kernel_ms'] * 1e3 / ev:.1f} us/event")
+names = ("A1 work list", "A2 rates+blocks", "B5 in-block choice", "C apply", "D field", "B1 sums+scan", "B2 draws", "B3 thread choice", "B4 block choice")
+for name, c in zip(names, r["exits"].ravel()[:9]):
+    print(f"   {name:18s} {c / ev:8.0f} cycles/event")
