@@ -107,13 +107,38 @@ def run_batched_exact(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var
             if getattr(ps, k) != getattr(first, k):
                 raise ValueError(f"run_batched_exact: systems differ in {k}")
     L, dx = first.L, first.dx
-    if L > GIL_MAX_L:
-        raise ValueError(f"L <= {GIL_MAX_L}: one system lives in one workgroup's LDS")
     inits = [ps.init_particles() for ps in systems]
     seed = first.seed if first.seed is not None else int(first.rng.random() * 2.0 ** 53)
     times_obs = np.arange(0.0, T, obs_dt)
     M = len(times_obs)
-    r = run_raw(L=L, K=first.K, periodic=first.periodic, sigma_grid=first._sigma_grid, rate_diffusion=first.rate_diffusion,
+    if L > GIL_MAX_L or max(len(p) for p, _ in inits) > GIL_MAX_N:
+        # beyond one workgroup's LDS: the large-system kernel (one system per launch, state in global memory)
+        if uniforms is not None:
+            raise ValueError("run_batched_exact: caller-supplied uniforms with large systems go through run_large_raw")
+        parts = []
+        for s, (ps, st) in enumerate(zip(systems, inits)):
+            one = run_large_raw(L=L, K=first.K, periodic=first.periodic, sigma_grid=first._sigma_grid, rate_diffusion=first.rate_diffusion,
+                                rate_active=first.rate_active, beta=float(ps.beta), state=st, times_obs=times_obs, T=T, seed=seed + s,
+                                minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
+                                suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,
+                                k_off=first.k_off, k_exit=first.k_exit, anchor_mask=first.is_anchor_site, device=first.device)
+            parts.append(one)
+        ncap = max(p["pos"].shape[1] for p in parts)
+
+        def stack(key, dtype):
+            out = np.zeros((len(parts), M, ncap), dtype)
+            for s, p in enumerate(parts):
+                out[s, :, :p[key].shape[1]] = p[key]
+            return out
+        exits = np.zeros((len(parts), ncap, 3))
+        for s, p in enumerate(parts):
+            exits[s, :p["exits"].shape[0]] = p["exits"]
+        r = dict(pos=stack("pos", np.int32), sigma=stack("sigma", np.int8), flags=stack("flags", np.uint8),
+                 n_recorded=np.array([p["n_recorded"] for p in parts]), n_events=np.array([p["n_events"] for p in parts]),
+                 t_final=np.array([p["t_final"] for p in parts]), exits=exits, n_exits=np.array([p["n_exits"] for p in parts]),
+                 n0=np.array([p["n0"] for p in parts]), kernel_ms=sum(p["kernel_ms"] for p in parts))
+    else:
+        r = run_raw(L=L, K=first.K, periodic=first.periodic, sigma_grid=first._sigma_grid, rate_diffusion=first.rate_diffusion,
                 rate_active=first.rate_active, betas=[float(ps.beta) for ps in systems], states=inits, times_obs=times_obs, T=T,
                 seed=seed, minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
                 suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,

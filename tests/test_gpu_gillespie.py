@@ -259,3 +259,20 @@ def test_large_system_kernel_same_uniforms_same_trajectory(gil, case):
     assert r["n_exits"] == len(exits[0])
     assert np.array_equal(r["exits"][:r["n_exits"], 1].astype(int), np.array(exits[1], dtype=int))
     assert ev > 300, (tag, ev)
+
+
+def test_mode_gillespie_gpu_dispatches_large_systems():
+    """N above one workgroup's capacity: ParticleSystem(mode="gillespie_gpu") goes through gil_run_large, same result contract."""
+    from PARTICLE_solver_CLASS import ParticleSystem
+    kw = dict(L=6000, xlim=1.0, rate_diffusion=0.3, rate_active=4.0, beta=1.0, init="fixed", N=3000, scale_rates=False,
+              local_kernel_sigma=0.005, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0, seed=5, mode="gillespie_gpu")
+    ps = ParticleSystem(rng=np.random.default_rng(2), **kw)
+    out = ps.run(T=0.3, obs_dt=0.05)
+    M = len(out["times_obs"])
+    assert M == 6 and all(p is not None and len(p) == 3000 for p in out["pos_list"])
+    assert all(np.bincount(p, minlength=6000).max() <= 1 for p in out["pos_list"])
+    assert np.allclose(out["total_list"].sum(axis=1) * ps.dx, 1.0) and ps.n_events > 1000
+    moved = np.abs(out["pos_list"][-1] - out["pos_list"][0])
+    assert moved.max() >= 1 and moved.max() < 40                  # nearest-neighbour hops only
+    again = ParticleSystem(rng=np.random.default_rng(2), **kw).run(T=0.3, obs_dt=0.05)
+    assert all(np.array_equal(a, b) for a, b in zip(out["pos_list"], again["pos_list"]))
