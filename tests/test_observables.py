@@ -38,3 +38,42 @@ def test_ensemble_statistics_reduction():
     m = np.array([r["m"] for r in rows])
     assert st["m_se"] == m.std(ddof=1) / np.sqrt(7)
     assert obs.ensemble_statistics(rows[:1])["std"] == 0.0
+
+
+def test_device_observables_formulas_match_reference_functions(golden):
+    """observables.DeviceObservables (the formulas applied to the integer sums the GPU kernels return) fed with the
+    same sums computed by NumPy from the fixture's frames must reproduce the reference's own observable functions
+    (fixture G7) -- pins the device-side path's host arithmetic without a GPU."""
+    obs = importlib.import_module(PKG + ".observables")
+    g = golden("g7_observables.npz")
+    for idx, c in enumerate(g.meta["cases"]):
+        pre = f"c{idx}_"
+        cuts = np.concatenate([[0], np.cumsum(g[pre + "pos_len"])])
+        cat = g[pre + "pos_cat"]
+        frames = [cat[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        if len({len(f) for f in frames}) != 1:
+            continue                                             # the device path is for runs without exits
+        times, L, dx = g[pre + "times_obs"], c["L"], c["dx"]
+        n = len(frames[0])
+        K = int(round(np.max(g[pre + "total_list"]) * n * dx))
+        acc = obs.DeviceObservables(times, L, dx, max(K, 1))
+        table = acc.block_table(n)
+        for k, p in enumerate(frames):
+            cp = np.rint(g[pre + "rho_p_list"][k] * n * dx).astype(int)
+            ct = np.rint(g[pre + "total_list"][k] * n * dx).astype(int)
+            cm = ct - cp
+            sums = dict(n=n, sum_sigma=int(round(g[pre + "m_global"][k] * n)), sum_pos=int(p.sum()), n_wall=int((p >= acc.x_wall).sum()),
+                        max_pos=int(p.max()), attempts=int(cp[:-1].sum()), blocked=int((cp[:-1] * table[cp[1:], cm[1:]]).sum()),
+                        sum_d=0, sum_d2=0, n_d=0)
+            if k >= acc.start:
+                d = p.astype(np.int64) - frames[acc.start]
+                sums.update(sum_d=int(d.sum()), sum_d2=int((d * d).sum()), n_d=n)
+            lo, hi = acc.front_range(sums["max_pos"])
+            acc.add(k, sums, int(((p >= lo) & (p <= hi)).sum()) if k >= acc.start else None)
+        row = acc.result()
+        assert row["window"] == (c["si"], c["ei"]), c["tag"]
+        np.testing.assert_allclose(row["v"], c["mean_v"], rtol=1e-9, atol=1e-13, err_msg=c["tag"])
+        np.testing.assert_allclose(row["m"], c["m"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(row["rho"], c["rho"], rtol=1e-9)
+        np.testing.assert_allclose(row["block"], c["blk"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(row["D"], c["D"], rtol=1e-7, atol=1e-16)
