@@ -762,7 +762,9 @@ struct FieldUpdArgs { int L, tlen, bshift, nb, dcap; double2 *ws; const uint32_t
 
 __host__ __device__ inline int fu_table_pad(int RS, int bshift) { return 64 * RS + (1 << bshift) + 2; }
 __host__ __device__ inline size_t fu_lds_bytes(int tlen, bool tab_lds, int RS, int bshift) {
-    const size_t table = tab_lds ? ((size_t)tlen + 2 + fu_table_pad(RS, bshift)) / 2 * 2 * sizeof(double) : 0;
+    // the whole (padded) table when it fits; otherwise a window of it per group of 32 buckets (interior tiles)
+    const size_t table = tab_lds ? ((size_t)tlen + 2 + fu_table_pad(RS, bshift)) / 2 * 2 * sizeof(double)
+                                 : ((size_t)(32 << bshift) + 64 * RS + 8) * sizeof(double);
     const size_t red = (size_t)FU_WAVES * 64 * RS * sizeof(double2);          // reuses the table's space after the sweep
     return (size_t)FU_WAVES * 2 * (FU_SEG + 4) * sizeof(uint32_t) + (table > red ? table : red);
 }
@@ -878,15 +880,27 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
     for (int r = 0; r < RS; ++r) { x8[r] = (uint32_t)min(x0 + r * 64 + lane, L - 1) << 3; accW[r] = accS[r] = 0.0; }
     __syncthreads();                                          // table staged
     FSTAMP(f_stage)
+    // Table too large for LDS: interior tiles stage, per group of 32 buckets, the window of the table that the group's
+    // distances to this tile can touch (<= 32 B + tile + 2 entries) and gather from that -- the sweep then reads LDS
+    // instead of sending 512 bytes per (deposit, 64-site tile) to L2.  Wall tiles and the torus keep the global path.
+    const bool windowed = !TAB_LDS && BC == 0 && !wall;
+    uint32_t win_base = 0;
+    if (!TAB_LDS) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        win_base = (uint32_t)(size_t)(lds_double *)tab;
+    }
+    const uint32_t win_lds = win_base;
+    int null_site = x0;                                       // site of the padding deposits (coefficients 0)
     int nseg = 0, nimg = 0;                                   // entries waiting in this wave's two segments
     const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg), *segi4 = reinterpret_cast<const uint4 *>(segi);
     auto flush = [&]() {                                      // sweep all SITES with the segments' deposits
-        if (lane < 4) { seg[nseg + lane] = DEP_NULL | (uint32_t)x0; segi[nimg + lane] = DEP_NULL | (uint32_t)x0; }   // pad to groups of four (a site of this tile: in table range)
+        if (lane < 4) { seg[nseg + lane] = DEP_NULL | (uint32_t)null_site; segi[nimg + lane] = DEP_NULL | (uint32_t)x0; }   // pad to groups of four (a site whose distances stay in table range)
         const int n4 = (nseg + 3) >> 2, ni4 = (nimg + 3) >> 2;
 #pragma unroll 1
         for (int i = 0; i < n4; ++i) {
             const uint4 q = seg4[i];                          // uniform address: LDS broadcast
             if (BC == 1) fu_group<1, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
+            else if (!TAB_LDS && windowed) fu_group<0, true, RS>(q, x8, win_base, table_g, tlen8, L8, accW, accS);
             else fu_group<0, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
         }
 #pragma unroll 1
@@ -898,6 +912,16 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
     };
     const int ngroups = (nbk + 31) >> 5;
     for (int j = 0; j < ngroups; ++j) {
+        if (!TAB_LDS && windowed) {
+            const int bs = b0 + j * 32, be = min(bs + 32, b0 + nbk);                    // buckets [bs, be) of this group
+            const int sA = max(0, (bs << a.bshift) - 1), sB = min(L - 1, be << a.bshift);   // their deposits' sites (one beyond each end)
+            const int dmin = max(0, max(x0 - sB, sA - x1)), dmax = max(x1 - sA, sB - x0);
+            __syncthreads();                                  // the previous group's sweep is done with the window
+            for (int i = t; i <= dmax - dmin; i += FU_THREADS) tab[i] = dmin + i < a.tlen ? table_g[dmin + i] : 0.0;
+            win_base = win_lds - ((uint32_t)dmin << 3);
+            null_site = min(max(x0, sA), sB);                 // its distances to the tile lie inside [dmin, dmax]
+            __syncthreads();
+        }
         const int bi = j * 32 + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
         int b = b0 + bi;
         if (b >= a.nb) b -= a.nb;
@@ -922,6 +946,7 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
             if (!__ballot(k0 + 8 < cnt)) break;               // no bucket of this wave has more
             ent = (k0 + 8 + slot < cnt) ? a.dep[((size_t)e * a.nb + b) * a.dcap + k0 + 8 + slot] : DEP_NULL;
         }
+        if (!TAB_LDS && windowed) flush();                    // this group's deposits against this group's window
     }
     FSTAMP(f_copy)
     flush();
