@@ -22,6 +22,7 @@
 // Compile with -ffp-contract=off: the rate/probability code is a fixed sequence of IEEE operations.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
@@ -1168,6 +1169,8 @@ struct aps_handle {
     bool profiling = false;
     std::vector<int> prof_kind;
     size_t prof_n = 0;
+    bool prof_dispatch = true;          // profiling runs: events attached to the kernel's own dispatch (else: events around it)
+    hipEvent_t k_start = nullptr, k_stop = nullptr;
     std::string err;
 };
 
@@ -1298,14 +1301,20 @@ PairArgs pair_args(aps_handle *h, bool hook, bool write_prop) {
 
 int prof_mark(aps_handle *h, int kind);
 
+// Every stepping kernel is launched through this: in a profiling run the start/stop events that prof_mark set up are
+// attached to the dispatch itself (begin/end timestamps of the kernel, what rocprofv3 reports), otherwise a plain launch.
+#define APS_K(h, kernel, grid, block, lds, ...) do { \
+        if ((h)->profiling && (h)->prof_dispatch) hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), (h)->stream, (h)->k_start, (h)->k_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, (h)->stream, __VA_ARGS__); } while (0)
+
 int launch_plan(aps_handle *h, int first_tile, int tile_cnt) {
     PlanArgs pa{h->p.L, h->tlen, (int)h->ntiles, first_tile, tile_cnt, h->plan_interval > 1 ? 2 * h->plan_interval : 0,
                 h->d_plan, h->d_plan_n};
     h->plan_age = 0;
     { int rc = prof_mark(h, 4 /* KIND_PLAN */); if (rc) return rc; }
     const dim3 grid((unsigned)((tile_cnt / RT + 3) / 4), (unsigned)h->E), block(256);
-    if (h->p.periodic) hipLaunchKernelGGL(plan_tiles<1>, grid, block, 0, h->stream, pa, h->d_tinfo);
-    else hipLaunchKernelGGL(plan_tiles<0>, grid, block, 0, h->stream, pa, h->d_tinfo);
+    if (h->p.periodic) APS_K(h, plan_tiles<1>, grid, block, 0, pa, h->d_tinfo);
+    else APS_K(h, plan_tiles<0>, grid, block, 0, pa, h->d_tinfo);
     HIP_TRY(h, hipGetLastError());
     return APS_OK;
 }
@@ -1337,13 +1346,13 @@ int launch_pair(aps_handle *h, const PairArgs &a, int first_tile, int tile_cnt) 
     const dim3 grid(std::max(1u, std::min((items + WAVES - 1) / WAVES, (unsigned)(h->num_cu * h->wgs_per_cu)))), block(NTHREADS);
     const size_t lds = lds_total_bytes(h->tlen, h->table_in_lds);
     { int rc = prof_mark(h, 0 /* KIND_PAIR */); if (rc) return rc; }   // events bracket the dominant kernel alone
-#define APS_LAUNCH(BC, TL) hipLaunchKernelGGL((pair_accumulate<BC, TL>), grid, block, lds, h->stream, b, h->d_sp8, h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
+#define APS_LAUNCH(BC, TL) APS_K(h, (pair_accumulate<BC, TL>), grid, block, lds, b, h->d_sp8, h->d_tinfo, h->d_table, h->d_plan, h->d_plan_n)
     if (h->p.periodic) { if (h->table_in_lds) APS_LAUNCH(1, true); else APS_LAUNCH(1, false); }
     else { if (h->table_in_lds) APS_LAUNCH(0, true); else APS_LAUNCH(0, false); }
 #undef APS_LAUNCH
     { int rc = prof_mark(h, 1 /* KIND_PROPOSE */); if (rc) return rc; }
     const dim3 pgrid((unsigned)((tile_cnt * TILE + 255) / 256), (unsigned)h->E);
-    hipLaunchKernelGGL(propose, pgrid, dim3(256), 0, h->stream, b);
+    APS_K(h, propose, pgrid, dim3(256), 0, b);
     HIP_TRY(h, hipGetLastError());
     return APS_OK;
 }
@@ -1415,15 +1424,22 @@ int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, i
 
 enum { KIND_PAIR = 0, KIND_PROPOSE, KIND_CLAIM, KIND_APPLY, KIND_PLAN, KIND_PROPOSE_LATTICE, KIND_FIELD_UPDATE, KIND_END, KIND_N = KIND_END };
 
-// profiling runs only: an event in front of the launch that follows (KIND_END closes the last one of a step)
+// profiling runs only.  Dispatch mode: hands the next APS_K launch a start/stop event pair of its own.  Bracket mode: an
+// event in front of the launch that follows (KIND_END closes the last one of a step).
 int prof_mark(aps_handle *h, int kind) {
     if (!h->profiling) return APS_OK;
-    if (h->prof_n >= h->events.size()) {
+    const size_t need = h->prof_dispatch ? 2 : 1;
+    if (h->prof_dispatch && kind == KIND_END) return APS_OK;
+    while (h->prof_n + need > h->events.size()) {
         hipEvent_t ev;
         HIP_TRY(h, hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    HIP_TRY(h, hipEventRecord(h->events[h->prof_n++], h->stream));
+    if (h->prof_dispatch) {
+        h->k_start = h->events[h->prof_n++]; h->k_stop = h->events[h->prof_n++];
+    } else {
+        HIP_TRY(h, hipEventRecord(h->events[h->prof_n++], h->stream));
+    }
     h->prof_kind.push_back(kind);
     return APS_OK;
 }
@@ -1470,7 +1486,7 @@ int launch_lattice_propose(aps_handle *h, const LatticeArgs &a, int first_tile, 
     int rc = prof_mark(h, KIND_PROPOSE_LATTICE);
     if (rc) return rc;
     const dim3 grid((unsigned)((tile_cnt * TILE + 255) / 256), (unsigned)h->E);
-    hipLaunchKernelGGL(propose_lattice, grid, dim3(256), 0, h->stream, b);
+    APS_K(h, propose_lattice, grid, dim3(256), 0, b);
     HIP_TRY(h, hipGetLastError());
     return APS_OK;
 }
@@ -1483,7 +1499,7 @@ int launch_field_update(aps_handle *h) {
     const int RS = h->fu_R;
     const dim3 grid((unsigned)((h->p.L + 64 * RS - 1) / (64 * RS)), (unsigned)h->E), block(FU_THREADS);
     const size_t lds = fu_lds_bytes(h->tlen, h->fu_table_in_lds, RS, h->bshift);
-#define APS_FU(BC, TL, RR) hipLaunchKernelGGL((field_update<BC, TL, RR>), grid, block, lds, h->stream, f, h->d_table)
+#define APS_FU(BC, TL, RR) APS_K(h, (field_update<BC, TL, RR>), grid, block, lds, f, h->d_table)
 #define APS_FU_R(BC, TL) do { switch (RS) { case 8: APS_FU(BC, TL, 8); break; case 7: APS_FU(BC, TL, 7); break; case 6: APS_FU(BC, TL, 6); break; \
         case 5: APS_FU(BC, TL, 5); break; case 4: APS_FU(BC, TL, 4); break; case 3: APS_FU(BC, TL, 3); break; default: APS_FU(BC, TL, 2); } } while (0)
     if (h->p.periodic) { if (h->fu_table_in_lds) APS_FU_R(1, true); else APS_FU_R(1, false); }
@@ -1509,10 +1525,10 @@ int do_commit(aps_handle *h) {
     int rc;
     if (h->world != 1) {                                     // one GPU: the propose kernel registered the hops
         if ((rc = prof_mark(h, KIND_CLAIM))) return rc;
-        hipLaunchKernelGGL(claim, grid, block, 0, h->stream, c);
+        APS_K(h, claim, grid, block, 0, c);
     }
     if ((rc = prof_mark(h, KIND_APPLY))) return rc;
-    hipLaunchKernelGGL(apply, grid, block, 0, h->stream, c);
+    APS_K(h, apply, grid, block, 0, c);
     HIP_TRY(h, hipGetLastError());
     h->step += 1;
     if (h->method == APS_METHOD_LATTICE) {
@@ -1820,11 +1836,18 @@ int run_profiled(aps_handle *h, int64_t nsteps, double ms[KIND_N], int64_t count
     std::vector<uint32_t> pn((size_t)h->E * std::max<int64_t>(h->ntiles / RT, h->nb));
     for (int64_t s = 0; s < nsteps; ++s) {
         h->profiling = true; h->prof_n = 0; h->prof_kind.clear();
+        h->prof_dispatch = std::getenv("APS_PROF_BRACKET") == nullptr;
         rc = one_step(h);
         h->profiling = false;
         if (rc) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        for (size_t i = 0; i + 1 < h->prof_n; ++i) {
+        if (h->prof_dispatch) {
+            for (size_t i = 0; i < h->prof_kind.size(); ++i) {
+                float t = 0.f;
+                HIP_TRY(h, hipEventElapsedTime(&t, h->events[2 * i], h->events[2 * i + 1]));
+                ms[h->prof_kind[i]] += t; counts[h->prof_kind[i]] += 1;
+            }
+        } else for (size_t i = 0; i + 1 < h->prof_n; ++i) {
             const int kind = h->prof_kind[i];
             if (kind == KIND_END) continue;
             float t = 0.f;
