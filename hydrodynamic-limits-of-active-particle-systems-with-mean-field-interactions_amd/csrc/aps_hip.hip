@@ -758,16 +758,19 @@ __global__ __launch_bounds__(256) void propose_lattice(const LatticeArgs a) {
 // four partial sums per site are added through LDS (exact on the weight grid, any order) and each site is
 // updated by exactly one thread: plain read-modify-write, no atomics.  Counters, list slots, table and the sites'
 // old values are all requested up front: the kernel pays ONE memory round trip before it computes.
-constexpr int FU_THREADS = 256, FU_WAVES = FU_THREADS / 64, FU_SEG = 256, FU_TREG = 16, FU_PRE = 2;
+constexpr int FU_THREADS = 256, FU_WAVES = FU_THREADS / 64, FU_SEG = 256, FU_SEG_WIN = 128, FU_WIN_BUCKETS = 16, FU_TREG = 16, FU_PRE = 2;
 struct FieldUpdArgs { int L, tlen, bshift, nb, dcap; double2 *ws; const uint32_t *dcnt, *dep; unsigned long long *stamps; };
 
 __host__ __device__ inline int fu_table_pad(int RS, int bshift) { return 64 * RS + (1 << bshift) + 2; }
+// table beyond LDS: entries of one window (the distances a group of FU_WIN_BUCKETS buckets can have to the tile), in
+// chunks of 128 entries = one LDS-direct load of a wave
+__host__ __device__ inline int fu_win_entries(int RS, int bshift) { return ((FU_WIN_BUCKETS << bshift) + 64 * RS + 8 + 127) / 128 * 128; }
 __host__ __device__ inline size_t fu_lds_bytes(int tlen, bool tab_lds, int RS, int bshift) {
-    // the whole (padded) table when it fits; otherwise a window of it per group of 32 buckets (interior tiles)
+    // the whole (padded) table when it fits; otherwise two windows of it (double buffer, interior tiles)
     const size_t table = tab_lds ? ((size_t)tlen + 2 + fu_table_pad(RS, bshift)) / 2 * 2 * sizeof(double)
-                                 : ((size_t)(32 << bshift) + 64 * RS + 8) * sizeof(double);
+                                 : (size_t)2 * fu_win_entries(RS, bshift) * sizeof(double);
     const size_t red = (size_t)FU_WAVES * 64 * RS * sizeof(double2);          // reuses the table's space after the sweep
-    return (size_t)FU_WAVES * 2 * (FU_SEG + 4) * sizeof(uint32_t) + (table > red ? table : red);
+    return (size_t)FU_WAVES * 2 * ((tab_lds ? FU_SEG : FU_SEG_WIN) + 4) * sizeof(uint32_t) + (table > red ? table : red);
 }
 
 // VAR: 0 = interior (no image term, padded table: no clamp), 1 = torus, 2 = reflecting wall in reach
@@ -811,12 +814,16 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
     constexpr int SITES = 64 * RS, NOLD = (SITES + FU_THREADS - 1) / FU_THREADS;
     extern __shared__ double lds[];
     const int tpad = TAB_LDS ? a.tlen + fu_table_pad(RS, a.bshift) : 0;        // last LDS table index (zeros beyond tlen - 1)
-    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds);                   // [FU_WAVES][2][FU_SEG + 4] deposits, then the table
-    double *tab = reinterpret_cast<double *>(seg_all + FU_WAVES * 2 * (FU_SEG + 4));
+    constexpr int SEG = TAB_LDS ? FU_SEG : FU_SEG_WIN;
+    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds);                   // [FU_WAVES][2][SEG + 4] deposits, then the table
+    double *tab = reinterpret_cast<double *>(seg_all + FU_WAVES * 2 * (SEG + 4));
     double2 *red = reinterpret_cast<double2 *>(tab);          // [FU_WAVES][SITES] partial sums, over the table once it is no longer read
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
-    uint32_t *seg = seg_all + wave * 2 * (FU_SEG + 4), *segi = seg + FU_SEG + 4;   // plain deposits / deposits with an image term
-    const int L = a.L, x0 = blockIdx.x * SITES, x1 = min(x0 + SITES - 1, L - 1);
+    uint32_t *seg = seg_all + wave * 2 * (SEG + 4), *segi = seg + SEG + 4;   // plain deposits / deposits with an image term
+    // table beyond LDS, reflecting walls: the tiles next to a wall gather from global memory and carry image deposits --
+    // several times the work of an interior tile -- so they are dealt first, from both ends inwards
+    const int tile = (BC == 0 && !TAB_LDS) ? ((blockIdx.x & 1) ? (int)gridDim.x - 1 - (int)(blockIdx.x >> 1) : (int)(blockIdx.x >> 1)) : (int)blockIdx.x;
+    const int L = a.L, x0 = tile * SITES, x1 = min(x0 + SITES - 1, L - 1);
     const int Rt = a.tlen - 1;                                // largest distance with a non-zero weight
 #ifdef APS_STAMPS
     unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
@@ -844,11 +851,15 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
     const bool wall = BC == 0 && ((x0 + 1 <= Rt) || (L - x1 <= Rt));   // an image term can be non-zero
     // Requests that depend on nothing: counters and first list slots of the first FU_PRE bucket groups (a group =
     // 32 buckets, 8 per wave, 8 slots each), the table, the sites' old values.
-    const int sub = lane >> 3, slot = lane & 7;
+    // lane = (bucket, list slot) of a load: 8 buckets x 8 slots per wave (groups of 32 buckets); with the table windowed,
+    // 4 buckets x 16 slots (groups of 16: half the window, so more workgroups per CU overlap staging and sweeping)
+    constexpr int SB = TAB_LDS ? 3 : 4, NSLOT = 1 << SB, GB = FU_WAVES * (64 >> SB);
+    static_assert(TAB_LDS || GB == FU_WIN_BUCKETS, "window size");
+    const int sub = lane >> SB, slot = lane & (NSLOT - 1);
     uint32_t pre_cnt[FU_PRE], pre_ent[FU_PRE];
 #pragma unroll
     for (int j = 0; j < FU_PRE; ++j) {
-        const int bi = j * 32 + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
+        const int bi = j * GB + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
         int b = b0 + bi;
         if (b >= a.nb) b -= a.nb;
         const bool ok = bi < nbk;
@@ -881,9 +892,12 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
     for (int r = 0; r < RS; ++r) { x8[r] = (uint32_t)min(x0 + r * 64 + lane, L - 1) << 3; accW[r] = accS[r] = 0.0; }
     __syncthreads();                                          // table staged
     FSTAMP(f_stage)
-    // Table too large for LDS: interior tiles stage, per group of 32 buckets, the window of the table that the group's
-    // distances to this tile can touch (<= 32 B + tile + 2 entries) and gather from that -- the sweep then reads LDS
-    // instead of sending 512 bytes per (deposit, 64-site tile) to L2.  Wall tiles and the torus keep the global path.
+    // Table too large for LDS: interior tiles keep, per group of GB = 16 buckets, the window of the table that the group's
+    // distances to this tile can touch (<= GB B + tile + 2 entries) in LDS and gather from that -- the sweep then reads LDS
+    // instead of sending 512 bytes per (deposit, 64-site tile) to L2.  The windows are double buffered and filled by
+    // LDS-direct loads (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no registers), issued one group
+    // ahead, so the sweep of group j hides the round trip of window j + 1.  The table in global memory is followed by
+    // zeros (see the allocation), so a window may run past its end.  Wall tiles and the torus keep the global path.
     const bool windowed = !TAB_LDS && BC == 0 && !wall;
     uint32_t win_base = 0;
     if (!TAB_LDS) {
@@ -891,7 +905,25 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
         win_base = (uint32_t)(size_t)(lds_double *)tab;
     }
     const uint32_t win_lds = win_base;
+    const int WIN = fu_win_entries(RS, a.bshift);
     int null_site = x0;                                       // site of the padding deposits (coefficients 0)
+    int dmin_next = 0, null_next = x0;
+    auto stage = [&](int j) {                                 // request window j into buffer j & 1
+        const int bs = b0 + j * GB, be = min(bs + GB, b0 + nbk);                        // buckets [bs, be) of this group
+        const int sA = max(0, (bs << a.bshift) - 1), sB = min(L - 1, be << a.bshift);   // their deposits' sites (one beyond each end)
+        const int dmin = max(0, max(x0 - sB, sA - x1)), dmax = max(x1 - sA, sB - x0), span = dmax - dmin;
+        // Written as inline assembly on purpose: the compiler orders every later LDS read behind a tracked LDS-direct load
+        // (s_waitcnt vmcnt(0) in front of the first ds_read of the sweep), which would serialise exactly what this hides.
+        // The explicit s_waitcnt vmcnt(0) + barrier at the top of the next group is the ordering that is needed.
+        const double *srcw = table_g + dmin + lane * 2;
+        const uint32_t dstw = win_lds + (uint32_t)((j & 1) * WIN) * 8u;
+        for (int c = wave; c * 128 <= span; c += FU_WAVES) {
+            const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dstw + (uint32_t)c * 1024u));
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srcw + c * 128) : "memory");
+        }
+        dmin_next = dmin;
+        null_next = min(max(x0, sA), sB);                     // its distances to the tile lie inside [dmin, dmax]
+    };
     int nseg = 0, nimg = 0;                                   // entries waiting in this wave's two segments
     const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg), *segi4 = reinterpret_cast<const uint4 *>(segi);
     auto flush = [&]() {                                      // sweep all SITES with the segments' deposits
@@ -911,43 +943,70 @@ __global__ __launch_bounds__(FU_THREADS) void field_update(const FieldUpdArgs a,
 #endif
         nseg = nimg = 0;
     };
-    const int ngroups = (nbk + 31) >> 5;
+    const int ngroups = (nbk + GB - 1) / GB;
+    if (!TAB_LDS && windowed) stage(0);
+    uint32_t nx_cnt = 0u, nx_ent = DEP_NULL;
     for (int j = 0; j < ngroups; ++j) {
-        if (!TAB_LDS && windowed) {
-            const int bs = b0 + j * 32, be = min(bs + 32, b0 + nbk);                    // buckets [bs, be) of this group
-            const int sA = max(0, (bs << a.bshift) - 1), sB = min(L - 1, be << a.bshift);   // their deposits' sites (one beyond each end)
-            const int dmin = max(0, max(x0 - sB, sA - x1)), dmax = max(x1 - sA, sB - x0);
-            __syncthreads();                                  // the previous group's sweep is done with the window
-            for (int i = t; i <= dmax - dmin; i += FU_THREADS) tab[i] = dmin + i < a.tlen ? table_g[dmin + i] : 0.0;
-            win_base = win_lds - ((uint32_t)dmin << 3);
-            null_site = min(max(x0, sA), sB);                 // its distances to the tile lie inside [dmin, dmax]
-            __syncthreads();
-        }
-        const int bi = j * 32 + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
+        const int bi = j * GB + sub * FU_WAVES + wave;          // buckets dealt to the waves round-robin: near-wall ones cost more
         int b = b0 + bi;
         if (b >= a.nb) b -= a.nb;
         const bool ok = bi < nbk;
-        uint32_t cnt, ent;
+        uint32_t cnt, ent;                                    // requested before the window is staged: one round trip for both
         if (j < FU_PRE) { cnt = j == 0 ? pre_cnt[0] : pre_cnt[FU_PRE - 1]; ent = j == 0 ? pre_ent[0] : pre_ent[FU_PRE - 1]; }
+        else if (!TAB_LDS) { cnt = nx_cnt; ent = nx_ent; }    // requested during the previous group's sweep
         else {
             cnt = ok ? a.dcnt[(size_t)e * a.nb + b] : 0u;
             ent = (ok && slot < a.dcap) ? a.dep[((size_t)e * a.nb + b) * a.dcap + slot] : DEP_NULL;
         }
-        cnt = min(cnt, (uint32_t)a.dcap);
-        for (uint32_t k0 = 0;; k0 += 8) {                     // 8 slots of the wave's 8 buckets per round
-            const bool valid = k0 + slot < cnt;
-            // near a reflecting wall only some deposits have an image in reach: x + p + 1 <= Rt or 2L - 1 - x - p <= Rt
-            const int dp = (int)(ent & POS_MASK);
-            const bool img = valid && wall && ((x0 + dp + 1 <= Rt) || (2 * L - 1 - x1 - dp <= Rt));
-            const unsigned long long m = __ballot(valid && !img), mi = __ballot(img);
-            if (nseg + 64 > FU_SEG || nimg + 64 > FU_SEG) flush();
-            if (valid && !img) seg[nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = ent;
-            if (img) segi[nimg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u))] = ent;
-            nseg += __popcll(m); nimg += __popcll(mi);
-            if (!__ballot(k0 + 8 < cnt)) break;               // no bucket of this wave has more
-            ent = (k0 + 8 + slot < cnt) ? a.dep[((size_t)e * a.nb + b) * a.dcap + k0 + 8 + slot] : DEP_NULL;
+        if (!TAB_LDS) {
+            FSTAMP(f_copy)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's chunks of window j have landed (and the list loads)
+            asm volatile("" : "+v"(cnt), "+v"(ent));          // the list words count as arrived: no wait on them once window j + 1 is in flight
         }
-        if (!TAB_LDS && windowed) flush();                    // this group's deposits against this group's window
+        if (!TAB_LDS && windowed) {
+            __syncthreads();                                  // ... everyone's; and every wave is done sweeping window j - 1
+            win_base = win_lds + (uint32_t)((j & 1) * WIN) * 8u - ((uint32_t)dmin_next << 3);
+            null_site = null_next;
+            if (j + 1 < ngroups) stage(j + 1);                // lands during this group's sweep
+            FSTAMP(f_cnt)
+        }
+        if (!TAB_LDS && j + 1 >= FU_PRE && j + 1 < ngroups) { // many groups per tile here: the next group's list words too
+            const int bi1 = (j + 1) * GB + sub * FU_WAVES + wave;
+            int b1 = b0 + bi1;
+            if (b1 >= a.nb) b1 -= a.nb;
+            const bool ok1 = bi1 < nbk;
+            nx_cnt = ok1 ? a.dcnt[(size_t)e * a.nb + b1] : 0u;
+            nx_ent = (ok1 && slot < a.dcap) ? a.dep[((size_t)e * a.nb + b1) * a.dcap + slot] : DEP_NULL;
+        }
+        cnt = min(cnt, (uint32_t)a.dcap);
+        // NSLOT slots of each of the wave's buckets: compact the valid ones into the wave's segments.  Near a reflecting
+        // wall only some deposits have an image in reach: x + p + 1 <= Rt or 2L - 1 - x - p <= Rt.
+#define FU_ROUND(EN, K0) { \
+            const bool valid = (K0) + slot < cnt; \
+            const int dp = (int)((EN) & POS_MASK); \
+            const bool img = valid && wall && ((x0 + dp + 1 <= Rt) || (2 * L - 1 - x1 - dp <= Rt)); \
+            const unsigned long long m = __ballot(valid && !img), mi = __ballot(img); \
+            if (nseg + 64 > SEG || nimg + 64 > SEG) flush(); \
+            if (valid && !img) seg[nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (EN); \
+            if (img) segi[nimg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u))] = (EN); \
+            nseg += __popcll(m); nimg += __popcll(mi); }
+        if (TAB_LDS) {
+            for (uint32_t k0 = 0;; k0 += NSLOT) {
+                FU_ROUND(ent, k0)
+                if (!__ballot(k0 + NSLOT < cnt)) break;       // no bucket of this wave has more
+                ent = (k0 + NSLOT + slot < cnt) ? a.dep[((size_t)e * a.nb + b) * a.dcap + k0 + NSLOT + slot] : DEP_NULL;
+            }
+        } else {
+            // first round peeled: inside a loop the compiler waits (vmcnt(0)) for the reload of `ent` before every use,
+            // and such a wait also waits for the next window, which is in flight on purpose
+            FU_ROUND(ent, 0u)
+            for (uint32_t k0 = NSLOT; __ballot(k0 < cnt); k0 += NSLOT) {
+                const uint32_t en = (k0 + slot < cnt) ? a.dep[((size_t)e * a.nb + b) * a.dcap + k0 + slot] : DEP_NULL;
+                FU_ROUND(en, k0)
+            }
+        }
+#undef FU_ROUND
+        if (!TAB_LDS && windowed) { FSTAMP(f_copy) flush(); FSTAMP(f_proc) }   // this group's deposits against this group's window
     }
     FSTAMP(f_copy)
     flush();
@@ -1639,7 +1698,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
         (rc = dev_alloc(h, &h->d_plan, (size_t)h->E * h->ntiles * PLAN_CAP)) || (rc = dev_alloc(h, &h->d_plan_n, (size_t)h->E * h->ntiles)) ||
         (rc = dev_alloc(h, &h->d_accW, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_accS, EN * MAX_SPLIT)) ||
         (rc = dev_alloc(h, &h->d_occ, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_pcnt, 2 * EL)) ||
-        (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size())) ||
+        (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size() + ((size_t)1 << h->bshift) + 1024)) ||
         (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)4 * h->E)) ||
         (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
         (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))
