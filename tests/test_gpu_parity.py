@@ -451,6 +451,35 @@ def test_table_too_large_for_lds_uses_global_table(capi, method):
         h.close()
 
 
+@pytest.mark.parametrize("periodic", [False, True], ids=["walls", "torus"])
+def test_windowed_table_dense_buckets(capi, periodic):
+    """Table beyond LDS (20 001 entries) with K = 3 at density 1.5 and a large dt: about 75 deposits per 256-site bucket
+    and step, so the list loads of `field_update` take several rounds per bucket, the wave segments are flushed inside a
+    group, and about 39 interior tiles go through the double-buffered table windows (walls; the torus, whose table has
+    L/2 + 1 entries, gathers from the table in global memory).  Same bit-exact bars."""
+    par = params(L=60000, K=3, sigma=5000.0 / 60000, periodic=periodic)
+    rng = np.random.default_rng(77)
+    N = 90000
+    pos, spin = random_state(rng, par.L, N, par.K)
+    orc = so.SyncOracle(par, dt=0.05, seed=21)
+    orc.set_state(pos, spin)
+    h = make_handle(capi, par, N, seed=21, method="lattice")
+    try:
+        assert len(h.table()[0]) == (30001 if periodic else 20001)
+        h.set_state(pos, spin)
+        for _ in range(2):
+            h.step(1)
+            orc.run(1)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin)
+            W, S, occ = h.get_lattice(0)
+            cp0, cm0, _ = orc.field_sites()
+            S0, W0 = orc.last_site_sums
+            assert np.array_equal(occ, cp0 + cm0) and np.array_equal(W, W0) and np.array_equal(S, S0)
+    finally:
+        h.close()
+
+
 def _random_case(rng):
     L = int(rng.choice([2, 3, 5, 17, 64, 129, 300, 777]))
     K = int(rng.integers(1, 6))
