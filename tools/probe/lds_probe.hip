@@ -1,3 +1,8 @@
+// Probe (GPU box): semantics of the LDS-direct load used by field_update's table windows on gfx950.
+// global_load_lds_dwordx4 via __builtin_amdgcn_global_load_lds(src, lds_dst, 16, 0, 0): every lane reads 16 bytes at ITS
+// global address (8-byte alignment is enough), the wave writes 64 x 16 contiguous bytes at the wave-uniform LDS address.
+// Build and run: hipcc --offload-arch=gfx950 -O3 tools/probe/lds_probe.hip -o /tmp/lds_probe && /tmp/lds_probe
+// Expected output: "off N: 0 mismatches" for the three source offsets.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
