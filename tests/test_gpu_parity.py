@@ -353,6 +353,36 @@ def test_config2_ten_thousand_steps_field_stays_exact(capi):
         b.close()
 
 
+def test_config5_scale_incremental_field_equals_from_scratch(capi):
+    """BASELINE config 5 scale (N = 1e6, L = 2e6, 40 001-entry table = 320 KB, beyond LDS): the field kept incrementally by
+    `field_update` (table windows in LDS for interior tiles, global gathers next to the walls) over 300 steps equals the one
+    a fresh handle builds from scratch from the final state with the `field_sites` kernel (itself pinned to the oracle at
+    the sizes the oracle can do), bit for bit on all 2e6 sites.  Too large for the CPU oracle: 8e10 table terms per field."""
+    L, N = 2_000_000, 1_000_000
+    par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7,
+                                       scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
+    rng = np.random.default_rng(11)
+    pos = rng.choice(L, size=N, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=N)
+    a = make_handle(capi, par, N, dt=0.0125, seed=4, method="lattice")
+    b = make_handle(capi, par, N, dt=0.0125, seed=4, method="lattice")
+    try:
+        assert len(a.table()[0]) == 40001
+        a.set_state(pos, spin)
+        a.step(300)
+        pa, sa, _, alive = a.get_state()
+        assert alive.all() and np.bincount(pa, minlength=L).max() <= 1 and (pa != pos).mean() > 0.3
+        b.set_state(pa, sa)
+        W, S, occ = a.get_lattice(0)
+        W0, S0, occ0 = b.get_lattice(0)
+        assert np.array_equal(occ, occ0) and np.array_equal(occ, np.bincount(pa, minlength=L))
+        assert np.array_equal(W, W0) and np.array_equal(S, S0)
+        assert W.min() > 0.0 and np.abs(S).max() <= W.max()
+    finally:
+        a.close()
+        b.close()
+
+
 def test_two_rank_shards_emulated_on_one_gpu(capi, method):
     """world=2 on ONE device: each handle evaluates its own particle shard, the proposal blocks are swapped
     by hand (what the all-gather does), both commit everything -> identical states, equal to world=1."""
