@@ -204,6 +204,68 @@ def bench_gillespie(args):
     print(json.dumps(out))
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, popen=None, port=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU) with the
+    torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), wait for all of them and relay
+    rank 0's single JSON line.  The parent never touches HIP or torch (a process that has initialised the GPU must not
+    be re-exec'd; here nothing is exec'd at all: the ranks are children).  Returns the exit code."""
+    import subprocess
+    popen = popen or subprocess.Popen
+    port = port or free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), APS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout carries the JSON line; the other ranks have nothing to say on stdout
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                           stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    # rank 0's pipe is drained by a thread so that a rank that dies early never leaves the others (blocked in a
+    # collective) running: as soon as one rank fails, the rest are ended -- by their own PIDs, nothing else
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read() if procs[0].stdout else ""), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except Exception:                        # noqa: BLE001
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        if out0:
+            print(out0, file=sys.stderr)
+        return next(c for c in codes if c) or 1
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +275,13 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "pde", "gillespie"] + sorted(EXTRA))
     ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs"])
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                                   # no launcher: this process only starts the ranks
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={os.environ['WORLD_SIZE']} of the launcher")
     if args.workload == "pde":
         return bench_pde(args)
     if args.workload == "gillespie":
@@ -248,20 +317,28 @@ def main():
         #   torch-nccl  torch.distributed backend "nccl" (= RCCL) on a torch tensor bound to the library
         #   gloo-host   host copies + gloo: always works (even with several ranks on one GPU); slow, last resort
         forced = os.environ.get("APS_BENCH_EXCHANGE", "")
-        run, path = None, ""
+        run, path, exchange, ranks_seen = None, "", "", None
         if forced in ("", "rccl"):
-            ok = True
-            try:
-                with stdout_to_stderr():
-                    ids = [capi.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(ids, src=0)
-                    h.comm_init(ids[0])
-                    h.step(1)                                # first collective (lazy channel setup) also under the redirect
-            except Exception as exc:                         # noqa: BLE001
-                ok = False
-                print(f"[rank {rank}] in-library RCCL unavailable ({exc})", file=sys.stderr)
+            ids = [None]
+            if rank == 0:                                    # a failure here must not unbalance the collectives below
+                try:
+                    with stdout_to_stderr():
+                        ids[0] = capi.comm_unique_id()
+                except Exception as exc:                     # noqa: BLE001
+                    print(f"[rank 0] in-library RCCL unavailable ({exc})", file=sys.stderr)
+            dist.broadcast_object_list(ids, src=0)
+            ok = ids[0] is not None
+            if ok:
+                try:
+                    with stdout_to_stderr():
+                        h.comm_init(ids[0])
+                        h.step(1)                            # first collective (lazy channel setup) also under the redirect
+                except Exception as exc:                     # noqa: BLE001
+                    ok = False
+                    print(f"[rank {rank}] in-library RCCL unavailable ({exc})", file=sys.stderr)
             if all_agree(ok):
-                run, path = h.step, "in-library RCCL all-gather"
+                run, path, exchange = h.step, "in-library RCCL all-gather", "rccl"
+                ranks_seen = h.comm_ranks()
             elif ok:                                         # this rank has a communicator the others lack: start over without it
                 h.close()
                 h = make_handle(capi, w, device=device, rank=rank, world=world, method=args.method)
@@ -279,13 +356,20 @@ def main():
                 ok = False
                 print(f"[rank {rank}] torch.distributed nccl unavailable ({exc})", file=sys.stderr)
             if all_agree(ok):
-                path = "torch.distributed nccl all_gather_into_tensor"
+                path, exchange = "torch.distributed nccl all_gather_into_tensor", "torch-nccl"
+                ranks_seen = dist.get_world_size(group)
 
                 def run(n, stepper=stepper):
                     stepper.step(n)
                     torch.cuda.synchronize()
         if run is None:
-            path = "host copies + torch.distributed gloo (fallback: no RCCL between these ranks)"
+            # only a rehearsal with several ranks on one GPU may fall back to host copies: with a device per rank the
+            # missing RCCL path is an error, not something to time and report as the multi-GPU result
+            if capi.device_count() >= world and forced != "gloo-host":
+                raise SystemExit(f"bench.py: rank {rank}: neither in-library RCCL nor torch.distributed nccl works between "
+                                 f"{world} ranks on {capi.device_count()} devices; refusing to time the host-copy fallback")
+            path, exchange = "host copies + torch.distributed gloo (rehearsal: several ranks share one GPU)", "gloo-host"
+            ranks_seen = dist.get_world_size()
             _, total, off, mine = h.exchange_buffer()
             buf = torch.zeros(total, dtype=torch.uint8, device=torch.device("cuda", device))
             h.set_stream(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
@@ -388,6 +472,8 @@ def main():
                    "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"
                                + (f" ({comm_path})" if sharded_path else "")},
     }
+    if sharded_path:
+        out["exchange"], out["ranks_seen"] = exchange, ranks_seen
     if roof:
         out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline and args.workload == "config2":

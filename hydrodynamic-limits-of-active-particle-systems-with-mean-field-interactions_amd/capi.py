@@ -111,6 +111,7 @@ def load():
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
+        "aps_comm_ranks": (C.c_int, [vp, P(i32)]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -230,6 +231,11 @@ class Handle:
     def comm_init(self, id128: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(id128)
         self._ck(self.lib.aps_comm_init(self._h, C.cast(buf, C.c_void_p)))
+
+    def comm_ranks(self):
+        n = C.c_int32()
+        self._ck(self.lib.aps_comm_ranks(self._h, C.byref(n)))
+        return n.value
 
     def step_timed(self, nsteps):
         ms, n, pairs = C.c_double(), C.c_int64(), C.c_double()

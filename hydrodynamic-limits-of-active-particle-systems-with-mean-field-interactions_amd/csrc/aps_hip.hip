@@ -1253,6 +1253,11 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
     bool load() {
@@ -1267,7 +1272,12 @@ struct Rccl {
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) {
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString || !CommCount || !Send || !Recv || !GroupStart || !GroupEnd) {
             err = "librccl lacks a required symbol"; lib = nullptr; return false;
         }
         return true;
@@ -2160,6 +2170,16 @@ int aps_comm_init(aps_handle *h, const uint8_t *id128) {
     std::memcpy(&id, id128, 128);
     const ncclResult_t nr = g_rccl.CommInitRank(&h->comm, h->world, id, h->rank);
     if (nr != ncclSuccess) { h->comm = nullptr; return fail(h, APS_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(nr)); }
+    return APS_OK;
+}
+
+int aps_comm_ranks(aps_handle *h, int32_t *nranks) {
+    if (!h || !nranks) return APS_ERR_ARG;
+    if (!h->comm) return fail(h, APS_ERR_STATE, "aps_comm_ranks: no communicator (aps_comm_init first)");
+    int n = 0;
+    const ncclResult_t nr = g_rccl.CommCount(h->comm, &n);
+    if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("ncclCommCount: ") + g_rccl.GetErrorString(nr));
+    *nranks = n;
     return APS_OK;
 }
 

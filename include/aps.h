@@ -120,6 +120,9 @@ int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes);
  * propose -> ncclAllGather (in place, 1 byte per particle, on the handle's stream) -> commit per step. */
 int aps_comm_unique_id(uint8_t *out128);
 int aps_comm_init(aps_handle *h, const uint8_t *id128);
+/* Number of ranks the communicator of this handle actually spans (ncclCommCount): what a bench line reports as
+ * evidence that the exchange ran between that many processes. */
+int aps_comm_ranks(aps_handle *h, int32_t *nranks);
 
 /* replaces the observation block (ref :517-536): site histograms and the m-field on all L sites. */
 int aps_observe(aps_handle *h, int32_t ensemble, int64_t *counts_p, int64_t *counts_m, double *m_field);
