@@ -18,8 +18,8 @@ LIB_PATH = os.path.join(HERE, "libaps_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "aps.h")
 
 APS_OK, APS_ERR_ARG, APS_ERR_HIP, APS_ERR_STATE, APS_ERR_NODEVICE = 0, -1, -2, -3, -4
-METHODS = {"auto": 0, "pairs": 1, "lattice": 2}          # APS_METHOD_* of include/aps.h
-KERNELS = ("pair_accumulate", "propose", "claim", "apply", "plan_tiles", "propose_lattice", "field_update")
+METHODS = {"auto": 0, "pairs": 1, "lattice": 2, "tiles": 3}          # APS_METHOD_* of include/aps.h
+KERNELS = ("pair_accumulate", "propose", "claim", "apply", "plan_tiles", "propose_lattice", "field_update", "tile_step")
 
 
 class ApsError(RuntimeError):
@@ -153,7 +153,7 @@ class Handle:
         rc = self.lib.aps_create(C.byref(par), C.byref(self._h))
         if rc != APS_OK:
             raise ApsError(rc, self.lib.aps_last_error(None).decode())
-        self.method = {1: "pairs", 2: "lattice"}[self.lib.aps_method(self._h)]
+        self.method = {1: "pairs", 2: "lattice", 3: "tiles"}[self.lib.aps_method(self._h)]
 
     # -- plumbing
     def _ck(self, rc):

@@ -1170,6 +1170,66 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
     }
 }
 
+#include "tile_step.hpp"
+
+// ---- site-centric state <-> particle-indexed arrays (observation, hooks, upload of the tiles method)
+// cells -> src (live particles only: an exit wrote its own record), occupancy per site
+__global__ __launch_bounds__(256) void cells_to_slots(const uint32_t *__restrict__ cell, const uint32_t *__restrict__ slot_of,
+                                                      uint32_t *src, uint32_t *occ_site, int L, int K, long long N, int Npad) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (s >= L) return;
+    int n = 0;
+    for (int k = 0; k < K; ++k) {
+        const uint32_t c = cell[((size_t)e * L + s) * K + k];
+        if (c == CELL_EMPTY) continue;
+        ++n;
+        src[(size_t)e * Npad + slot_of[(size_t)e * N + (c & CELL_ID)]] =
+            (uint32_t)s | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
+    }
+    occ_site[(size_t)e * L + s] = (uint32_t)n;
+}
+
+// src -> pre-decoded source words and per-tile info (what apply() maintains in the particle-indexed formulations)
+__global__ __launch_bounds__(256) void derive_slots(const uint32_t *__restrict__ src, uint32_t *sp8, int4 *tinfo, int Npad, int ntiles) {
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    const uint32_t me = src[(size_t)e * Npad + slot];
+    const bool live = !(me & DEAD_BIT);
+    const int p = (int)(me & POS_MASK);
+    sp8[(size_t)e * Npad + slot] = live ? (((uint32_t)p << 3) | ((me & SPIN_BIT) ? 1u : 0u)) : DEAD_P8;
+    int lo = live ? p : 0x7fffffff, hi = live ? p : -1, cnt = live ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); cnt += __shfl_xor(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) tinfo[(size_t)e * ntiles + slot / TILE] = make_int4(lo, hi, cnt < TILE ? 1 : 0, cnt);
+}
+
+// per-tile spin sum / live count of the cells (global-field mode), and their total into gsum
+__global__ __launch_bounds__(256) void tile_parts(const uint32_t *__restrict__ cell, long long *gpart, long long *gsum, int L, int K, int own, int ntile) {
+    const int tile = blockIdx.x, e = blockIdx.y;
+    const int s0 = tile * own, s1 = min(s0 + own, L);
+    long long sp = 0, n = 0;
+    for (int i = threadIdx.x; i < (s1 - s0) * K; i += blockDim.x) {
+        const uint32_t c = cell[((size_t)e * L + s0) * K + i];
+        if (c != CELL_EMPTY) { sp += (c & CELL_PLUS) ? 1 : -1; n += 1; }
+    }
+    __shared__ long long acc[2];
+    if (threadIdx.x == 0) acc[0] = acc[1] = 0;
+    __syncthreads();
+    const long long a0 = wave_sum(sp), a1 = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[0]), (unsigned long long)a0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[1]), (unsigned long long)a1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gpart[((size_t)e * ntile + tile) * 2] = acc[0]; gpart[((size_t)e * ntile + tile) * 2 + 1] = acc[1];
+        atomicAdd(reinterpret_cast<unsigned long long *>(&gsum[2 * e]), (unsigned long long)acc[0]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&gsum[2 * e + 1]), (unsigned long long)acc[1]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 std::string g_create_error;
 
@@ -1221,6 +1281,15 @@ struct aps_handle {
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     int graph_steps = 0;
+    // tiles formulation (site-centric state, one kernel per step): everything double buffered by step parity
+    double2 *d_wsb[2] = {nullptr, nullptr};
+    uint32_t *d_cell[2] = {nullptr, nullptr}, *d_tdcnt[2] = {nullptr, nullptr}, *d_tdep[2] = {nullptr, nullptr};
+    long long *d_gpart[2] = {nullptr, nullptr};
+    uint32_t *d_slot_of = nullptr;
+    int ts_RS = 2, ts_own = 124, ts_ntile = 0, ts_dcap = 0;
+    bool ts_table_in_lds = true;
+    bool slots_dirty = false;                  // the particle-indexed arrays lag behind the cells
+    bool field_pending = false;                // the last step's deposits are not yet added to ws[cur]
     uint32_t *d_ref = nullptr, *d_cnt_pm = nullptr;   // observables: reference state per slot [E][Npad], per-site counts [L]
     uint8_t *d_block_table = nullptr, *d_ref_ok = nullptr; long long *d_scal = nullptr; int *d_lo_hi = nullptr;
     std::vector<char> ref_set;                         // per ensemble: reference marked (and slot order unchanged since)
@@ -1491,7 +1560,7 @@ int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, i
     return APS_OK;
 }
 
-enum { KIND_PAIR = 0, KIND_PROPOSE, KIND_CLAIM, KIND_APPLY, KIND_PLAN, KIND_PROPOSE_LATTICE, KIND_FIELD_UPDATE, KIND_END, KIND_N = KIND_END };
+enum { KIND_PAIR = 0, KIND_PROPOSE, KIND_CLAIM, KIND_APPLY, KIND_PLAN, KIND_PROPOSE_LATTICE, KIND_FIELD_UPDATE, KIND_TILE_STEP, KIND_END, KIND_N = KIND_END };
 
 // profiling runs only.  Dispatch mode: hands the next APS_K launch a start/stop event pair of its own.  Bracket mode: an
 // event in front of the launch that follows (KIND_END closes the last one of a step).
@@ -1530,7 +1599,10 @@ LatticeArgs lattice_args(aps_handle *h, bool hook, bool write_prop) {
 int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, int ntiles, double *m_out, double2 *ws_out);
 
 // (re)build W, S on all sites from the particles (state upload; afterwards the field is kept incrementally)
+int ensure_tiles(aps_handle *h);
+
 int ensure_lattice(aps_handle *h) {
+    if (h->method == APS_METHOD_TILES) return ensure_tiles(h);
     if (h->method != APS_METHOD_LATTICE) return APS_OK;
     if (h->field_dirty) {
         if (h->model.field_mode)
@@ -1579,7 +1651,154 @@ int launch_field_update(aps_handle *h) {
     return APS_OK;
 }
 
+
+// ------------------------------------------------------------------------------- tiles formulation, host side
+bool is_tiles(const aps_handle *h) { return h->method == APS_METHOD_TILES; }
+
+const void *ts_kernel(bool periodic, bool tab, int RS) {
+#define TS_CASE(R) case R: return periodic ? (tab ? (const void *)&tile_step<1, true, R> : (const void *)&tile_step<1, false, R>) \
+                                            : (tab ? (const void *)&tile_step<0, true, R> : (const void *)&tile_step<0, false, R>);
+    switch (RS) { TS_CASE(1) TS_CASE(2) TS_CASE(3) TS_CASE(4) TS_CASE(5) TS_CASE(6) TS_CASE(8) default: return nullptr; }
+#undef TS_CASE
+}
+constexpr int TS_RS_CHOICES[] = {1, 2, 3, 4, 5, 6, 8};
+
+// tile geometry: the frame size (64 RS sites) that gives about 2.4 workgroups per CU, table in LDS when it fits
+void ts_choose_geometry(aps_handle *h) {
+    const int L = h->p.L;
+    h->ts_RS = 1;
+    double best = 1e300;
+    for (int rs : TS_RS_CHOICES) {
+        const int own = 64 * rs - 4;
+        const double wgs = (double)(((int64_t)L + own - 1) / own) * h->E;
+        const double miss = std::fabs(wgs - 2.4 * 256.0);
+        if (miss < best) { best = miss; h->ts_RS = rs; }
+    }
+    if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r)) h->ts_RS = r; }
+    h->ts_own = 64 * h->ts_RS - 4;
+    h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
+    h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
+    h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K).total <= 160 * 1024;
+}
+
+TileArgs tile_args(aps_handle *h, bool field_only) {
+    TileArgs a{};
+    const int par = (int)(h->step & 1), out = field_only ? par : par ^ 1;
+    a.m = h->model; a.tlen = h->tlen; a.own = h->ts_own; a.ntile = h->ts_ntile; a.dcap = h->ts_dcap; a.E = h->E; a.par = par;
+    a.tile_lo = 0; a.field_only = field_only ? 1 : 0;
+    a.ws_in = h->d_wsb[par]; a.ws_out = h->d_wsb[out];
+    a.cell_in = h->d_cell[par]; a.cell_out = h->d_cell[par ^ 1];
+    a.dcnt_in = h->d_tdcnt[par]; a.dep_in = h->d_tdep[par]; a.dcnt_out = h->d_tdcnt[par ^ 1]; a.dep_out = h->d_tdep[par ^ 1];
+    a.gpart_in = h->d_gpart[par]; a.gpart_out = h->d_gpart[par ^ 1];
+    a.stepw = h->d_stepw; a.beta = h->d_beta; a.anchor = h->d_anchor;
+    a.exit_log = h->d_exit; a.n_exit = h->d_nexit; a.exit_cap = h->exit_cap;
+    a.src = h->d_src; a.slot_of = h->d_slot_of; a.Npad = (int)h->Npad; a.N = h->N; a.stamps = h->d_stamps;
+    return a;
+}
+
+int launch_tile_step(aps_handle *h, bool field_only = false) {
+    int rc = field_only ? APS_OK : prof_mark(h, KIND_TILE_STEP);
+    if (rc) return rc;
+    TileArgs a = tile_args(h, field_only);
+    const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS);
+    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K).total;
+    const dim3 grid((unsigned)h->ts_ntile, (unsigned)h->E), block(FU_THREADS);
+    void *args[] = {(void *)&a, (void *)&h->d_table};
+    if (!field_only && h->profiling && h->prof_dispatch)
+        HIP_TRY(h, hipExtLaunchKernel(fn, grid, block, args, lds, h->stream, h->k_start, h->k_stop, 0));
+    else
+        HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, lds, h->stream));
+    if (!field_only) { h->slots_dirty = true; h->field_pending = true; }
+    return APS_OK;
+}
+
+// add the deposits of the last step to W, S now (the next step would do it first thing): afterwards ws[cur] is the field
+// of the current cells.  Exact arithmetic: when the deposits are added changes no bit of any later result.
+int flush_field(aps_handle *h) {
+    if (!is_tiles(h) || !h->field_pending) return APS_OK;
+    const int cur = (int)(h->step & 1);
+    if (h->model.field_mode) {
+        int rc = launch_tile_step(h, true);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_tdcnt[cur], 0, (size_t)h->E * h->ts_ntile * 4, h->stream));
+    if (h->gexec) { /* captured kernels read the same buffers: nothing to rebuild */ }
+    h->field_pending = false;
+    return APS_OK;
+}
+
+// bring the particle-indexed arrays (src, sp8, tinfo, occ_site, gsum) up to date with the cells
+int sync_slots(aps_handle *h) {
+    if (!is_tiles(h)) return APS_OK;
+    int rc = flush_field(h);
+    if (rc) return rc;
+    const int cur = (int)(h->step & 1);
+    h->d_ws = h->d_wsb[cur];
+    if (!h->slots_dirty) return APS_OK;
+    const int L = h->p.L;
+    hipLaunchKernelGGL(cells_to_slots, dim3((unsigned)((L + 255) / 256), (unsigned)h->E), dim3(256), 0, h->stream,
+                       h->d_cell[cur], h->d_slot_of, h->d_src, h->d_occ_site, L, h->p.K, (long long)h->N, (int)h->Npad);
+    hipLaunchKernelGGL(derive_slots, dim3((unsigned)(h->Npad / 256), (unsigned)h->E), dim3(256), 0, h->stream,
+                       h->d_src, h->d_sp8, h->d_tinfo, (int)h->Npad, (int)h->ntiles);
+    long long *gs = h->d_gsum + (size_t)cur * 2 * h->E;
+    HIP_TRY(h, hipMemsetAsync(gs, 0, (size_t)2 * h->E * sizeof(long long), h->stream));
+    hipLaunchKernelGGL(tile_parts, dim3((unsigned)h->ts_ntile, (unsigned)h->E), dim3(256), 0, h->stream,
+                       h->d_cell[cur], h->d_gpart[cur], gs, L, h->p.K, h->ts_own, h->ts_ntile);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->slots_dirty = false;
+    h->plan_dirty = true;
+    return APS_OK;
+}
+
+// (re)build everything the tile kernel reads from the uploaded particles: W, S on all sites, no pending deposits,
+// the per-tile parts of the global sums, the step words
+int ensure_tiles(aps_handle *h) {
+    if (!h->field_dirty) return APS_OK;
+    const int cur = (int)(h->step & 1), L = h->p.L;
+    if (h->model.field_mode)
+        for (int e = 0; e < h->E; ++e) {
+            int rc = launch_field(h, e, h->d_sp8 + (size_t)e * h->Npad, h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles,
+                                  nullptr, h->d_wsb[cur] + (size_t)e * L);
+            if (rc) return rc;
+        }
+    HIP_TRY(h, hipMemsetAsync(h->d_tdcnt[cur], 0, (size_t)h->E * h->ts_ntile * 4, h->stream));
+    long long *gs = h->d_gsum + (size_t)cur * 2 * h->E;
+    HIP_TRY(h, hipMemsetAsync(gs, 0, (size_t)2 * h->E * sizeof(long long), h->stream));
+    hipLaunchKernelGGL(tile_parts, dim3((unsigned)h->ts_ntile, (unsigned)h->E), dim3(256), 0, h->stream,
+                       h->d_cell[cur], h->d_gpart[cur], gs, L, h->p.K, h->ts_own, h->ts_ntile);
+    HIP_TRY(h, hipGetLastError());
+    const unsigned long long sw[2] = {(unsigned long long)(h->step & 1 ? h->step - 1 : h->step), (unsigned long long)(h->step & 1 ? h->step : h->step + 1)};
+    HIP_TRY(h, hipMemcpyAsync(h->d_stepw, sw, sizeof(sw), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->d_ws = h->d_wsb[cur];
+    h->field_dirty = false;
+    h->field_pending = false;
+    return APS_OK;
+}
+
+// cells + id -> slot map of one ensemble, from the caller's arrays and the slot order pack_ensemble chose
+int upload_cells(aps_handle *h, int e, const int32_t *pos, const int8_t *sigma, const uint8_t *bound, const uint8_t *alive, int64_t n,
+                 const std::vector<uint32_t> &orig) {
+    const int L = h->p.L, K = h->p.K, cur = (int)(h->step & 1);
+    std::vector<uint32_t> cells((size_t)L * K, CELL_EMPTY), slot_of((size_t)std::max<int64_t>(h->N, 1), 0u);
+    std::vector<int> fill((size_t)L, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (alive && !alive[i]) continue;
+        uint32_t c = (uint32_t)i;
+        if (sigma[i] > 0) c |= CELL_PLUS;
+        if (bound && bound[i]) c |= CELL_BOUND;
+        cells[(size_t)pos[i] * K + (size_t)fill[(size_t)pos[i]]++] = c;
+    }
+    for (int64_t sl = 0; sl < h->Npad; ++sl) if (orig[(size_t)sl] != 0xFFFFFFFFu) slot_of[orig[(size_t)sl]] = (uint32_t)sl;
+    HIP_TRY(h, hipMemcpyAsync(h->d_cell[cur] + (size_t)e * L * K, cells.data(), cells.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_slot_of + (size_t)e * h->N, slot_of.data(), (size_t)h->N * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
 int do_propose(aps_handle *h) {
+    if (is_tiles(h)) return launch_tile_step(h);
     if (h->method == APS_METHOD_LATTICE) {
         const LatticeArgs a = lattice_args(h, false, true);
         return launch_lattice_propose(h, a, a.tile_lo, a.tile_cnt);
@@ -1589,6 +1808,7 @@ int do_propose(aps_handle *h) {
 }
 
 int do_commit(aps_handle *h) {
+    if (is_tiles(h)) { h->step += 1; return prof_mark(h, KIND_END); }   // the tile kernel already wrote the new state
     const CommitArgs c = commit_args(h);
     const dim3 grid((unsigned)(h->Npad / 256), (unsigned)h->E), block(256);
     int rc;
@@ -1641,7 +1861,8 @@ int aps_create(const aps_params *p, aps_handle **out) {
     if (!(p->dt > 0.0)) return bad("dt must be > 0");
     if (!p->beta) return bad("beta pointer is null");
     if (p->world < 1 || p->rank < 0 || p->rank >= p->world) return bad("bad rank/world");
-    if (p->method != APS_METHOD_AUTO && p->method != APS_METHOD_PAIRS && p->method != APS_METHOD_LATTICE) return bad("method must be APS_METHOD_AUTO, _PAIRS or _LATTICE");
+    if (p->method != APS_METHOD_AUTO && p->method != APS_METHOD_PAIRS && p->method != APS_METHOD_LATTICE && p->method != APS_METHOD_TILES)
+        return bad("method must be APS_METHOD_AUTO, _PAIRS, _LATTICE or _TILES");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "aps_create: no HIP device"; return APS_ERR_NODEVICE; }
     if (p->device < 0 || p->device >= ndev) return bad("device ordinal out of range");
@@ -1671,11 +1892,16 @@ int aps_create(const aps_params *p, aps_handle **out) {
         h->nb = (p->L + B - 1) / B;
         h->dcap = (int)std::min<int64_t>(2LL * p->K * B, std::max<int64_t>(2 * p->n_particles, 2));
         const double dep_bytes = (double)h->E * h->nb * h->dcap * 4.0;
-        h->method = p->method == APS_METHOD_AUTO ? (dep_bytes <= 16e9 ? APS_METHOD_LATTICE : APS_METHOD_PAIRS) : p->method;
+        // tiles: site-centric state, one kernel per step (single GPU handles; ids must fit the 30-bit cell field)
+        const bool tiles_ok = p->world == 1 && p->n_particles < (int64_t)CELL_ID && dep_bytes <= 16e9;
+        if (p->method == APS_METHOD_TILES && !tiles_ok) { delete h; return bad("method tiles needs world = 1 and fewer than 2^30 - 1 particles"); }
+        h->method = p->method == APS_METHOD_AUTO ? (tiles_ok ? APS_METHOD_TILES : (dep_bytes <= 16e9 ? APS_METHOD_LATTICE : APS_METHOD_PAIRS)) : p->method;
         if (const char *env = std::getenv("APS_METHOD")) {    // test / tuning knob for method = auto
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "pairs")) h->method = APS_METHOD_PAIRS;
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "lattice")) h->method = APS_METHOD_LATTICE;
+            if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "tiles") && tiles_ok) h->method = APS_METHOD_TILES;
         }
+        ts_choose_geometry(h);
         // sites per lane of field_update: the largest tile that still gives about two workgroups per CU
         // sites per lane of field_update (tile = 64 * RS sites per workgroup): about 2.4 workgroups per CU was the
         // fastest grid on MI355X (measured, RS = 5 at L = 2e5); large lattices take the largest tile (fewest table copies)
@@ -1720,6 +1946,25 @@ int aps_create(const aps_params *p, aps_handle **out) {
             (rc = dev_alloc(h, &h->d_stepw, 2)))
             return die(rc);
     }
+    if (h->method == APS_METHOD_TILES) {
+        const size_t ET = (size_t)h->E * h->ts_ntile;
+        if ((rc = dev_alloc(h, &h->d_occ_site, EL)) || (rc = dev_alloc(h, &h->d_stepw, 2)) ||
+            (rc = dev_alloc(h, &h->d_slot_of, (size_t)h->E * std::max<int64_t>(h->N, 1))))
+            return die(rc);
+        for (int b = 0; b < 2; ++b) {
+            if ((rc = dev_alloc(h, &h->d_wsb[b], EL)) || (rc = dev_alloc(h, &h->d_cell[b], EL * p->K)) ||
+                (rc = dev_alloc(h, &h->d_tdcnt[b], ET)) || (rc = dev_alloc(h, &h->d_tdep[b], ET * h->ts_dcap)) ||
+                (rc = dev_alloc(h, &h->d_gpart[b], ET * 2)))
+                return die(rc);
+            if (hipMemsetAsync(h->d_cell[b], 0xFF, EL * p->K * 4, h->stream) != hipSuccess) { h->err = "cell init failed"; return die(APS_ERR_HIP); }
+        }
+        const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K).total;
+        if (need > 160 * 1024) { h->err = "tiles: site capacity too large for the tile kernel's LDS staging"; return die(APS_ERR_ARG); }
+        if (need > 48 * 1024 &&
+            hipFuncSetAttribute(ts_kernel(p->periodic != 0, h->ts_table_in_lds, h->ts_RS), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
+            h->err = "hipFuncSetAttribute(tile_step) failed"; return die(APS_ERR_HIP);
+        }
+    }
     if (p->anchor_mask) {
         if ((rc = dev_alloc(h, &h->d_anchor, (size_t)p->L))) return die(rc);
         if (hipMemcpyAsync(h->d_anchor, p->anchor_mask, (size_t)p->L, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "anchor upload failed"; return die(APS_ERR_HIP); }
@@ -1739,6 +1984,10 @@ void aps_destroy(aps_handle *h) {
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
+    for (int b = 0; b < 2; ++b)
+        for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
+    if (h->d_slot_of) (void)hipFree(h->d_slot_of);
     for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_lo_hi, (void *)h->d_ref_ok, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
@@ -1767,9 +2016,11 @@ int aps_set_state(aps_handle *h, int32_t e, const int32_t *pos, const int8_t *si
         if (!(alive && !alive[i]) && ++occ[(size_t)pos[i]] > h->p.K) return fail(h, APS_ERR_ARG, "aps_set_state: site capacity exceeded");
     }
     std::vector<uint32_t> src, orig; long long gsum[2];
-    pack_ensemble(h, pos, sigma, bound, alive, n, src, orig, gsum);
-    int rc = upload_ensemble(h, e, src, orig);
+    int rc = sync_slots(h);                                  // the other ensembles' particle-indexed arrays must be current
     if (rc) return rc;
+    pack_ensemble(h, pos, sigma, bound, alive, n, src, orig, gsum);
+    if ((rc = upload_ensemble(h, e, src, orig))) return rc;
+    if (is_tiles(h) && (rc = upload_cells(h, e, pos, sigma, bound, alive, n, orig))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_gsum + (size_t)(h->step & 1) * 2 * h->E + 2 * e, gsum, sizeof(gsum), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_nexit + e, 0, sizeof(unsigned), h->stream));
     if (h->d_occ_site) {
@@ -1788,6 +2039,7 @@ int aps_get_state(aps_handle *h, int32_t e, int32_t *pos, int8_t *sigma, uint8_t
     if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_get_state: bad ensemble");
     if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_get_state: no state uploaded for this ensemble");
     if (n != h->n_set[(size_t)e]) return fail(h, APS_ERR_ARG, "aps_get_state: n differs from the uploaded particle count");
+    { int rc_ = sync_slots(h); if (rc_) return rc_; }
     std::vector<uint32_t> src((size_t)h->Npad), orig((size_t)h->Npad);
     HIP_TRY(h, hipMemcpyAsync(src.data(), h->d_src + (size_t)e * h->Npad, src.size() * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(orig.data(), h->d_orig + (size_t)e * h->Npad, orig.size() * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1810,6 +2062,7 @@ int aps_pair_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t 
     if (e < 0 || e >= h->E || !S || !W || !occ4) return fail(h, APS_ERR_ARG, "aps_pair_accumulate: bad argument");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_pair_accumulate: upload a state for every ensemble first");
     if (n != h->n_set[(size_t)e]) return fail(h, APS_ERR_ARG, "aps_pair_accumulate: n differs from the uploaded particle count");
+    { int rc_ = sync_slots(h); if (rc_) return rc_; }
     const size_t EN = (size_t)h->E * (size_t)h->Npad;
     int rc;
     if (!h->d_S && ((rc = dev_alloc(h, &h->d_S, EN)) || (rc = dev_alloc(h, &h->d_W, EN)) || (rc = dev_alloc(h, &h->d_occ4, EN * 4)))) return rc;
@@ -1902,7 +2155,7 @@ int run_profiled(aps_handle *h, int64_t nsteps, double ms[KIND_N], int64_t count
     if (work) *work = 0.0;
     int rc = ensure_lattice(h);
     if (rc) return rc;
-    std::vector<uint32_t> pn((size_t)h->E * std::max<int64_t>(h->ntiles / RT, h->nb));
+    std::vector<uint32_t> pn((size_t)h->E * std::max<int64_t>(std::max<int64_t>(h->ntiles / RT, h->nb), h->ts_ntile));
     for (int64_t s = 0; s < nsteps; ++s) {
         h->profiling = true; h->prof_n = 0; h->prof_kind.clear();
         h->prof_dispatch = std::getenv("APS_PROF_BRACKET") == nullptr;
@@ -1926,7 +2179,12 @@ int run_profiled(aps_handle *h, int64_t nsteps, double ms[KIND_N], int64_t count
         if (work && (s == 0 || s == nsteps - 1)) {           // the work per step changes slowly: sample first and last step
             const double wgt = nsteps == 1 ? 1.0 : 0.5 * (double)nsteps;
             double t = 0.0;
-            if (h->method == APS_METHOD_LATTICE) {           // deposits of the step just taken
+            if (is_tiles(h)) {                               // deposits of the step just taken (read by the next step)
+                if (h->model.field_mode) {
+                    HIP_TRY(h, hipMemcpy(pn.data(), h->d_tdcnt[h->step & 1], (size_t)h->E * h->ts_ntile * 4, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < (size_t)h->E * h->ts_ntile; ++i) t += (double)pn[i];
+                }
+            } else if (h->method == APS_METHOD_LATTICE) {    // deposits of the step just taken
                 if (h->model.field_mode) {
                     HIP_TRY(h, hipMemcpy(pn.data(), h->d_dcnt, (size_t)h->E * h->nb * 4, hipMemcpyDeviceToHost));
                     for (size_t i = 0; i < (size_t)h->E * h->nb; ++i) t += (double)pn[i];
@@ -1955,12 +2213,13 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     if (rc) return rc;
     int64_t s = 0;
     static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
-    if (h->method == APS_METHOD_LATTICE && h->world == 1 && !no_graph && nsteps > 0) {
+    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps > 0) {
         if ((rc = build_graph(h))) return rc;                              // once per handle, on the first stepping call
         if ((h->step & 1) && nsteps - s > h->graph_steps) { if ((rc = one_step(h))) return rc; ++s; }   // replays start on even steps
         for (; !(h->step & 1) && nsteps - s >= h->graph_steps; s += h->graph_steps) {
             HIP_TRY(h, hipGraphLaunch(h->gexec, h->stream));
             h->step += h->graph_steps;
+            if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; }
         }
     }
     for (; s < nsteps; ++s)
@@ -1977,21 +2236,21 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *la
     double ms[KIND_N]; int64_t cnt[KIND_N];
     int rc = run_profiled(h, nsteps, ms, cnt, work);
     if (rc) return rc;
-    const int kind = h->method == APS_METHOD_LATTICE ? KIND_FIELD_UPDATE : KIND_PAIR;
+    const int kind = is_tiles(h) ? KIND_TILE_STEP : (h->method == APS_METHOD_LATTICE ? KIND_FIELD_UPDATE : KIND_PAIR);
     *kernel_ms = ms[kind];
     if (launches) *launches = cnt[kind];
     return APS_OK;
 }
 
-int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launches7) {
+int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms8, int64_t *launches8) {
     if (!h) return APS_ERR_ARG;
-    if (nsteps < 0 || !ms7) return fail(h, APS_ERR_ARG, "aps_step_profile: bad argument");
+    if (nsteps < 0 || !ms8) return fail(h, APS_ERR_ARG, "aps_step_profile: bad argument");
     if (h->world != 1) return fail(h, APS_ERR_STATE, "aps_step_profile: sharded handle");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step_profile: upload a state for every ensemble first");
     double ms[KIND_N]; int64_t cnt[KIND_N];
     int rc = run_profiled(h, nsteps, ms, cnt, nullptr);
     if (rc) return rc;
-    for (int k = 0; k < KIND_N; ++k) { ms7[k] = ms[k]; if (launches7) launches7[k] = cnt[k]; }
+    for (int k = 0; k < KIND_N; ++k) { ms8[k] = ms[k]; if (launches8) launches8[k] = cnt[k]; }
     return APS_OK;
 }
 
@@ -1999,6 +2258,7 @@ int aps_mark_reference(aps_handle *h, int32_t e) {
     if (!h) return APS_ERR_ARG;
     if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_mark_reference: bad ensemble");
     if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_mark_reference: no state uploaded for this ensemble");
+    { int rc_ = sync_slots(h); if (rc_) return rc_; }
     int rc;
     if (!h->d_ref && (rc = dev_alloc(h, &h->d_ref, (size_t)h->E * h->Npad))) return rc;
     if (h->ref_set.empty()) h->ref_set.assign((size_t)h->E, 0);
@@ -2016,6 +2276,7 @@ int observe_scalars_impl(aps_handle *h, int e0, int n, int32_t x_wall, const int
                          const uint8_t *block_table, int64_t *out11) {
     const int K = h->p.K, L = h->p.L;
     int rc;
+    if ((rc = sync_slots(h))) return rc;
     if (!h->d_scal && ((rc = dev_alloc(h, &h->d_scal, (size_t)16 * h->E)) || (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L * h->E)) ||
                        (rc = dev_alloc(h, &h->d_block_table, (size_t)(K + 1) * (K + 1))) || (rc = dev_alloc(h, &h->d_lo_hi, (size_t)2 * h->E)) ||
                        (rc = dev_alloc(h, &h->d_ref_ok, (size_t)h->E)))) return rc;
@@ -2087,13 +2348,13 @@ int aps_event_overhead(aps_handle *h, int32_t reps, double *ms_per_pair) {
 int aps_lattice_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32_t *occ4, int64_t n) {
     if (!h) return APS_ERR_ARG;
     if (e < 0 || e >= h->E || !S || !W || !occ4) return fail(h, APS_ERR_ARG, "aps_lattice_accumulate: bad argument");
-    if (h->method != APS_METHOD_LATTICE) return fail(h, APS_ERR_STATE, "aps_lattice_accumulate: handle uses the all-pairs formulation");
+    if (h->method != APS_METHOD_LATTICE && !is_tiles(h)) return fail(h, APS_ERR_STATE, "aps_lattice_accumulate: handle uses the all-pairs formulation");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_lattice_accumulate: upload a state for every ensemble first");
     if (n != h->n_set[(size_t)e]) return fail(h, APS_ERR_ARG, "aps_lattice_accumulate: n differs from the uploaded particle count");
     const size_t EN = (size_t)h->E * (size_t)h->Npad;
     int rc;
     if (!h->d_S && ((rc = dev_alloc(h, &h->d_S, EN)) || (rc = dev_alloc(h, &h->d_W, EN)) || (rc = dev_alloc(h, &h->d_occ4, EN * 4)))) return rc;
-    if ((rc = ensure_lattice(h))) return rc;
+    if ((rc = ensure_lattice(h)) || (rc = sync_slots(h))) return rc;
     const LatticeArgs a = lattice_args(h, true, false);
     if ((rc = launch_lattice_propose(h, a, 0, (int)h->ntiles))) return rc;
     return download_hook(h, e, S, W, occ4);
@@ -2102,10 +2363,10 @@ int aps_lattice_accumulate(aps_handle *h, int32_t e, double *S, double *W, int32
 int aps_get_lattice(aps_handle *h, int32_t e, double *W, double *S, int32_t *occ) {
     if (!h) return APS_ERR_ARG;
     if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_get_lattice: bad ensemble");
-    if (h->method != APS_METHOD_LATTICE) return fail(h, APS_ERR_STATE, "aps_get_lattice: handle uses the all-pairs formulation");
+    if (h->method != APS_METHOD_LATTICE && !is_tiles(h)) return fail(h, APS_ERR_STATE, "aps_get_lattice: handle uses the all-pairs formulation");
     if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_get_lattice: no state uploaded for this ensemble");
     int rc = ensure_lattice(h);
-    if (rc) return rc;
+    if (rc || (rc = sync_slots(h))) return rc;
     const size_t L = (size_t)h->p.L;
     if (W || S) {
         std::vector<double2> ws(L, make_double2(0.0, 0.0));
@@ -2265,7 +2526,7 @@ int aps_get_exits(aps_handle *h, int32_t e, double *rows3, int64_t cap_rows, int
 
 int aps_resort(aps_handle *h) {
     if (!h) return APS_ERR_ARG;
-    if (!h->p.sort_by_site) return APS_OK;
+    if (!h->p.sort_by_site || is_tiles(h)) return APS_OK;   // the tile kernel does not care about the slot order
     for (int e = 0; e < h->E; ++e) {
         const int64_t n = h->n_set[(size_t)e];
         if (n < 0) continue;
@@ -2292,6 +2553,7 @@ int aps_observe(aps_handle *h, int32_t e, int64_t *counts_p, int64_t *counts_m, 
     if (!h) return APS_ERR_ARG;
     if (e < 0 || e >= h->E) return fail(h, APS_ERR_ARG, "aps_observe: bad ensemble");
     if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_observe: no state uploaded for this ensemble");
+    { int rc_ = sync_slots(h); if (rc_) return rc_; }
     const int L = h->p.L;
     if (counts_p || counts_m) {
         std::vector<uint32_t> src((size_t)h->Npad);

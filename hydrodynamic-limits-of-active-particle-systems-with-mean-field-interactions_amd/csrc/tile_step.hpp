@@ -1,0 +1,441 @@
+// tile_step.hpp -- the whole synchronous step as ONE kernel over site tiles (included by aps_hip.hip, inside its
+// anonymous namespace, after field_update's helpers).
+//
+// Hot path replaced: the body of ParticleSystem.run's loop (PARTICLE_solver_CLASS.py:511-516), i.e.
+// compute_local_m_field (:216-246) + step_gillespie (:254-448) in the fixed-dt synchronous scheme of DESIGN.md 3.
+//
+// State is SITE-CENTRIC and double buffered by step parity (read [par], write [par ^ 1]):
+//   cell [E][L][K] u32   one word per particle slot of a site: id (bits 0-29) | bound << 30 | plus << 31, or CELL_EMPTY
+//                        (_build_occupancy, ref :248-252, is the number of non-empty cells of a site)
+//   ws   [E][L] double2  {W = tot_conv, S = s_conv} (ref :224-238, unnormalised taps on the weight grid)
+//   dep  [E][T][dcap], dcnt [E][T]   field changes ("deposits") made by the particles of tile t in the previous step
+// A workgroup owns OWN = 64 RS - 4 consecutive sites and computes on a frame of 64 RS sites (2 halo sites on either
+// side).  One step of a tile:
+//   1  add every deposit of the previous step that reaches the frame to W, S of the frame sites (field_update's sweep)
+//   2  proposals of every particle on the frame (rates -> Philox -> event), from the fresh field and the cells
+//   3  exclusion: hops into a site are granted in increasing particle id while capacity lasts (the proposers of a site
+//      sit on its two neighbours, so two halo sites decide every hop from or into an owned site)
+//   4  new cells of the owned sites (stayers + granted arrivals), the tile's deposit list for the next step, exits
+// Neighbouring tiles recompute the same halo proposals from the same inputs (exact arithmetic, counter-based random
+// numbers), so no tile ever waits for another: the kernel boundary is the only synchronisation of a step, nothing is
+// atomic in global memory except the exit log, and a site range of tiles can live on another GPU (halo = 3 sites of
+// cells, 2 sites of ws and the deposit lists within the table's reach).
+#pragma once
+
+constexpr uint32_t CELL_EMPTY = 0xFFFFFFFFu, CELL_ID = 0x3FFFFFFFu, CELL_BOUND = 1u << 30, CELL_PLUS = 1u << 31;
+constexpr int TS_CREG = 4;                 // cell words a thread can stage through registers in the prologue
+
+struct TileArgs {
+    Model m;
+    int tlen, own, ntile, dcap, E, par, tile_lo, field_only;
+    const double2 *ws_in; double2 *ws_out;             // [E][L]
+    const uint32_t *cell_in; uint32_t *cell_out;       // [E][L][K]
+    const uint32_t *dcnt_in, *dep_in;                  // [E][ntile], [E][ntile][dcap]: written by the previous step
+    uint32_t *dcnt_out, *dep_out;
+    const long long *gpart_in; long long *gpart_out;   // [E][ntile][2] spin sum / live count per tile (global-field mode)
+    unsigned long long *stepw;                         // [2] device step words (see propose_lattice)
+    const double *beta; const uint8_t *anchor;
+    double *exit_log; unsigned *n_exit; int exit_cap;
+    uint32_t *src; const uint32_t *slot_of;            // particle-indexed record, touched only by exits
+    int Npad; long long N;
+    unsigned long long *stamps;
+};
+
+// slots per bucket and load, buckets per group: TAB_LDS 4 buckets x 16 slots per wave (16 buckets per group);
+// table windowed: 2 buckets x 32 slots (8 per group), so that a group's window stays near 4096 + tile entries
+template <bool TAB_LDS> struct TsGeom { static constexpr int SB = TAB_LDS ? 4 : 5, NSLOT = 1 << SB, GB = FU_WAVES * (64 >> SB); };
+
+__host__ __device__ inline int ts_table_pad(int RS, int own) { return 64 * RS + own + 2; }
+__host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TsGeom<false>::GB * own) + 64 * RS + 8 + 127) / 128 * 128; }
+struct TsLds { size_t seg, cells, props, occ, misc, tab, total; };
+__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K) {
+    TsLds l;
+    const size_t TS = 64 * (size_t)RS;
+    l.seg = 0;
+    l.cells = l.seg + (size_t)FU_WAVES * 2 * ((tab_lds ? FU_SEG : FU_SEG_WIN) + 4) * sizeof(uint32_t);
+    l.props = l.cells + ((TS + 2) * K * 4 + 7) / 8 * 8;
+    l.occ = l.props + (TS * K + 7) / 8 * 8;
+    l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
+    l.tab = l.misc + 64;
+    const size_t table = tab_lds ? ((size_t)tlen + 2 + ts_table_pad(RS, own)) / 2 * 2 * sizeof(double)
+                                 : (size_t)2 * ts_win_entries(RS, own) * sizeof(double);
+    const size_t red = (size_t)FU_WAVES * TS * sizeof(double2);
+    l.total = l.tab + (table > red ? table : red);
+    return l;
+}
+
+template <int BC, bool TAB_LDS, int RS>
+__global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const double *__restrict__ table_g) {
+    constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS;
+    constexpr int SEG = TAB_LDS ? FU_SEG : FU_SEG_WIN;
+    constexpr int SB = TsGeom<TAB_LDS>::SB, NSLOT = TsGeom<TAB_LDS>::NSLOT, GB = TsGeom<TAB_LDS>::GB;
+    extern __shared__ double lds[];
+    const Model &M = a.m;
+    const int L = M.L, K = M.K, OWN = a.own;
+    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K);
+    char *lds_c = reinterpret_cast<char *>(lds);
+    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
+    uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame sites -1 .. TS
+    uint8_t *propL = reinterpret_cast<uint8_t *>(lds_c + lay.props);         // [TS K]
+    uint8_t *occL = reinterpret_cast<uint8_t *>(lds_c + lay.occ);            // [TS + 2]
+    int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // [0] deposits of this tile, [1] spin sum, [2] live count
+    double *tab = reinterpret_cast<double *>(lds_c + lay.tab);
+    double2 *red = reinterpret_cast<double2 *>(tab);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
+    uint32_t *seg = seg_all + wave * 2 * (SEG + 4), *segi = seg + SEG + 4;
+    const int tile = a.tile_lo + (int)blockIdx.x;
+    const int own0 = tile * OWN, own_n = min(OWN, L - own0), nfr = own_n + 4;   // owned sites, valid frame positions
+    const int x0 = own0 - 2;                                   // site of frame position 0 (may lie outside the lattice)
+    const int x0c = max(x0, 0), x1c = min(x0 + TS - 1, L - 1); // the frame clipped to the lattice (range tests)
+    const int Rt = a.tlen - 1;
+    const unsigned long long step = a.stepw[a.par];
+    if (blockIdx.x == 0 && e == 0 && t == 0 && !a.field_only) a.stepw[a.par ^ 1] = step + 1ull;   // nobody reads that word during this step
+    // site of frame position i (position -1 .. TS); -1 = no such site (beyond a wall, or beyond the valid frame)
+    auto frame_site = [&](int i) -> int {
+        if (i < -1 || i > nfr) return -1;
+        int s = x0 + i;
+        if (BC == 1) { s %= L; if (s < 0) s += L; return s; }
+        return (s < 0 || s >= L) ? -1 : s;
+    };
+#ifdef APS_STAMPS
+    unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_part = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long f_start = t0, r_start = __builtin_amdgcn_s_memrealtime();
+#define TSTAMP(var) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - t0; t0 = t1_; }
+#else
+#define TSTAMP(var)
+#endif
+    // ---------------------------------------------------------------- requests that depend on nothing
+    // cells of the frame (+1 site either side) through registers when they fit, else by a plain loop
+    const int ncell = (TS + 2) * K;
+    uint32_t creg[TS_CREG];
+    const bool cells_in_regs = ncell <= TS_CREG * FU_THREADS;
+    if (cells_in_regs) {
+#pragma unroll
+        for (int u = 0; u < TS_CREG; ++u) {
+            const int c = t + u * FU_THREADS;
+            const int s = c < ncell ? frame_site(c / K - 1) : -1;
+            creg[u] = s >= 0 ? a.cell_in[((size_t)e * L + s) * K + c % K] : CELL_EMPTY;
+        }
+    } else {
+        for (int c = t; c < ncell; c += FU_THREADS) {
+            const int s = frame_site(c / K - 1);
+            cellL[c] = s >= 0 ? a.cell_in[((size_t)e * L + s) * K + c % K] : CELL_EMPTY;
+        }
+    }
+    // buckets (= tiles) whose deposits can reach the frame: one run of nbk buckets from b0 that may wrap around the torus
+    int b0 = 0, nbk = 0;
+    if (M.field_mode) {
+        if (BC == 0) {
+            b0 = max(0, x0c - Rt - 1) / OWN;
+            nbk = min(L - 1, x1c + Rt + 1) / OWN - b0 + 1;
+        } else {
+            const int lo = x0 - Rt - 1, hi = x0 + TS - 1 + Rt + 1;
+            if (hi - lo + 1 >= L) { b0 = 0; nbk = a.ntile; }
+            else {
+                const int lom = ((lo % L) + L) % L, him = ((hi % L) + L) % L;
+                const int blo = lom / OWN, bhi = him / OWN;
+                b0 = blo;
+                nbk = (lom <= him) ? bhi - blo + 1 : (a.ntile - blo) + bhi + 1;
+                if (nbk > a.ntile) { b0 = 0; nbk = a.ntile; }
+            }
+        }
+    }
+    const bool wall = BC == 0 && ((x0c + 1 <= Rt) || (L - x1c <= Rt));   // an image term can be non-zero
+    const int sub = lane >> SB, slot = lane & (NSLOT - 1);
+    uint32_t pre_cnt[FU_PRE], pre_ent[FU_PRE];
+#pragma unroll
+    for (int j = 0; j < FU_PRE; ++j) {
+        const int bi = j * GB + sub * FU_WAVES + wave;
+        int b = b0 + bi;
+        if (b >= a.ntile) b -= a.ntile;
+        const bool ok = bi < nbk;
+        pre_cnt[j] = ok ? a.dcnt_in[(size_t)e * a.ntile + b] : 0u;
+        pre_ent[j] = (ok && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + slot] : DEP_NULL;
+    }
+    double tv[FU_TREG];
+    if (TAB_LDS) {
+#pragma unroll
+        for (int u = 0; u < FU_TREG; ++u) { const int i = t + u * FU_THREADS; tv[u] = i < a.tlen ? table_g[i] : 0.0; }
+    }
+    double2 old[NOLD];
+#pragma unroll
+    for (int r = 0; r < NOLD; ++r) {
+        const int xi = r * FU_THREADS + t;
+        const int s = (xi < TS && xi < nfr) ? frame_site(xi) : -1;
+        old[r] = (s >= 0 && M.field_mode) ? a.ws_in[(size_t)e * L + s] : make_double2(0.0, 0.0);
+    }
+    // global-field mode (ref :219-221): the sums over all particles = sum of the tiles' parts
+    long long gS = 0, gN = 0;
+    if (!M.field_mode) {
+        for (int i = t; i < a.ntile; i += FU_THREADS) { gS += a.gpart_in[((size_t)e * a.ntile + i) * 2]; gN += a.gpart_in[((size_t)e * a.ntile + i) * 2 + 1]; }
+    }
+    if (t < 8) misc[t] = 0;
+    if (cells_in_regs) {
+#pragma unroll
+        for (int u = 0; u < TS_CREG; ++u) { const int c = t + u * FU_THREADS; if (c < ncell) cellL[c] = creg[u]; }
+    }
+    const int tpad = TAB_LDS ? a.tlen + ts_table_pad(RS, OWN) : 0;
+    uint32_t tbase = 0;
+    if (TAB_LDS) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        tbase = (uint32_t)(size_t)(lds_double *)tab;
+#pragma unroll
+        for (int u = 0; u < FU_TREG; ++u) { const int i = t + u * FU_THREADS; if (i <= tpad) tab[i] = tv[u]; }
+        for (int i = t + FU_TREG * FU_THREADS; i <= tpad; i += FU_THREADS) tab[i] = i < a.tlen ? table_g[i] : 0.0;
+    }
+    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)L << 3;
+    uint32_t x8[RS];
+    double accW[RS], accS[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        int s = x0 + r * 64 + lane;
+        if (BC == 1) { s %= L; if (s < 0) s += L; } else s = min(max(s, 0), L - 1);
+        x8[r] = (uint32_t)s << 3; accW[r] = accS[r] = 0.0;
+    }
+    __syncthreads();                                           // table and cells staged
+    TSTAMP(f_stage)
+    // ---------------------------------------------------------------- 1  deposits of the previous step -> W, S of the frame
+    const bool windowed = !TAB_LDS && BC == 0 && !wall;
+    uint32_t win_base = 0;
+    if (!TAB_LDS) {
+        typedef __attribute__((address_space(3))) double lds_double;
+        win_base = (uint32_t)(size_t)(lds_double *)tab;
+    }
+    const uint32_t win_lds = win_base;
+    const int WIN = ts_win_entries(RS, OWN);
+    int null_site = x0c;
+    int dmin_next = 0, null_next = x0c;
+    auto stage = [&](int j) {                                  // request window j into buffer j & 1 (see field_update)
+        const int bs = b0 + j * GB, be = min(bs + GB, b0 + nbk);
+        const int sA = max(0, bs * OWN - 1), sB = min(L - 1, be * OWN);
+        const int dmin = max(0, max(x0c - sB, sA - x1c)), dmax = max(x1c - sA, sB - x0c), span = dmax - dmin;
+        const double *srcw = table_g + dmin + lane * 2;
+        const uint32_t dstw = win_lds + (uint32_t)((j & 1) * WIN) * 8u;
+        for (int c = wave; c * 128 <= span; c += FU_WAVES) {
+            const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dstw + (uint32_t)c * 1024u));
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srcw + c * 128) : "memory");
+        }
+        dmin_next = dmin;
+        null_next = min(max(x0c, sA), sB);
+    };
+    int nseg = 0, nimg = 0;
+    const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg), *segi4 = reinterpret_cast<const uint4 *>(segi);
+    auto flush = [&]() {
+        if (lane < 4) { seg[nseg + lane] = DEP_NULL | (uint32_t)null_site; segi[nimg + lane] = DEP_NULL | (uint32_t)x0c; }
+        const int n4 = (nseg + 3) >> 2, ni4 = (nimg + 3) >> 2;
+#pragma unroll 1
+        for (int i = 0; i < n4; ++i) {
+            const uint4 q = seg4[i];
+            if (BC == 1) fu_group<1, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
+            else if (!TAB_LDS && windowed) fu_group<0, true, RS>(q, x8, win_base, table_g, tlen8, L8, accW, accS);
+            else fu_group<0, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
+        }
+#pragma unroll 1
+        for (int i = 0; i < ni4; ++i) fu_group<2, TAB_LDS, RS>(segi4[i], x8, tbase, table_g, tlen8, L8, accW, accS);
+#ifdef APS_STAMPS
+        f_n += nseg + nimg;
+#endif
+        nseg = nimg = 0;
+    };
+    const int ngroups = (nbk + GB - 1) / GB;
+    if (!TAB_LDS && windowed && ngroups > 0) stage(0);
+    uint32_t nx_cnt = 0u, nx_ent = DEP_NULL;
+    for (int j = 0; j < ngroups; ++j) {
+        const int bi = j * GB + sub * FU_WAVES + wave;
+        int b = b0 + bi;
+        if (b >= a.ntile) b -= a.ntile;
+        const bool ok = bi < nbk;
+        uint32_t cnt, ent;
+        if (j < FU_PRE) { cnt = j == 0 ? pre_cnt[0] : pre_cnt[FU_PRE - 1]; ent = j == 0 ? pre_ent[0] : pre_ent[FU_PRE - 1]; }
+        else if (!TAB_LDS) { cnt = nx_cnt; ent = nx_ent; }
+        else {
+            cnt = ok ? a.dcnt_in[(size_t)e * a.ntile + b] : 0u;
+            ent = (ok && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + slot] : DEP_NULL;
+        }
+        if (!TAB_LDS) {
+            TSTAMP(f_copy)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(cnt), "+v"(ent));
+        }
+        if (!TAB_LDS && windowed) {
+            __syncthreads();
+            win_base = win_lds + (uint32_t)((j & 1) * WIN) * 8u - ((uint32_t)dmin_next << 3);
+            null_site = null_next;
+            if (j + 1 < ngroups) stage(j + 1);
+            TSTAMP(f_cnt)
+        }
+        if (!TAB_LDS && j + 1 >= FU_PRE && j + 1 < ngroups) {
+            const int bi1 = (j + 1) * GB + sub * FU_WAVES + wave;
+            int b1 = b0 + bi1;
+            if (b1 >= a.ntile) b1 -= a.ntile;
+            const bool ok1 = bi1 < nbk;
+            nx_cnt = ok1 ? a.dcnt_in[(size_t)e * a.ntile + b1] : 0u;
+            nx_ent = (ok1 && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b1) * a.dcap + slot] : DEP_NULL;
+        }
+        cnt = min(cnt, (uint32_t)a.dcap);
+#define TS_ROUND(EN, K0) { \
+            const bool valid = (K0) + slot < cnt; \
+            const int dp = (int)((EN) & POS_MASK); \
+            const bool img = valid && wall && ((x0c + dp + 1 <= Rt) || (2 * L - 1 - x1c - dp <= Rt)); \
+            const unsigned long long mm = __ballot(valid && !img), mi = __ballot(img); \
+            if (nseg + 64 > SEG || nimg + 64 > SEG) flush(); \
+            if (valid && !img) seg[nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (EN); \
+            if (img) segi[nimg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u))] = (EN); \
+            nseg += __popcll(mm); nimg += __popcll(mi); }
+        if (TAB_LDS) {
+            for (uint32_t k0 = 0;; k0 += NSLOT) {
+                TS_ROUND(ent, k0)
+                if (!__ballot(k0 + NSLOT < cnt)) break;
+                ent = (k0 + NSLOT + slot < cnt) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + k0 + NSLOT + slot] : DEP_NULL;
+            }
+        } else {
+            TS_ROUND(ent, 0u)
+            for (uint32_t k0 = NSLOT; __ballot(k0 < cnt); k0 += NSLOT) {
+                const uint32_t en = (k0 + slot < cnt) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + k0 + slot] : DEP_NULL;
+                TS_ROUND(en, k0)
+            }
+        }
+#undef TS_ROUND
+        if (!TAB_LDS && windowed) { TSTAMP(f_copy) flush(); TSTAMP(f_proc) }
+    }
+    TSTAMP(f_copy)
+    flush();
+    TSTAMP(f_proc)
+    __syncthreads();                                           // every wave is done with the table: its space takes the partial sums
+#pragma unroll
+    for (int r = 0; r < RS; ++r) red[(size_t)wave * TS + r * 64 + lane] = make_double2(accW[r], accS[r]);
+    // occupancy of the frame sites (-1 .. TS) from the staged cells
+    for (int i = t; i < TS + 2; i += FU_THREADS) {
+        int n = 0;
+        for (int k = 0; k < K; ++k) n += cellL[i * K + k] != CELL_EMPTY;
+        occL[i] = (uint8_t)n;
+    }
+    if (!M.field_mode) {                                       // workgroup sums of the global-field parts
+        const long long s1 = wave_sum(gS), s2 = wave_sum(gN);
+        if (lane == 0) { atomicAdd(&misc[4 + 0], (int)s1); atomicAdd(&misc[4 + 1], (int)s2); }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- 2  fresh field + proposals of the frame's particles
+    const double beta = a.beta[e];
+    double2 fnew[NOLD];
+#pragma unroll
+    for (int r = 0; r < NOLD; ++r) {
+        const int xi = r * FU_THREADS + t;
+        fnew[r] = old[r];
+        if (xi < TS && xi < nfr) {
+#pragma unroll
+            for (int w = 0; w < FU_WAVES; ++w) { const double2 pth = red[(size_t)w * TS + xi]; fnew[r].x += pth.x; fnew[r].y += pth.y; }
+            const int s = frame_site(xi);
+            if (s >= 0) {
+                if (M.field_mode && xi >= 2 && xi < 2 + own_n) a.ws_out[(size_t)e * L + s] = fnew[r];
+                double fW = fnew[r].x, fS = fnew[r].y;
+                if (!M.field_mode) { fS = (double)misc[4]; fW = (double)misc[5]; }
+                const int c0 = occL[xi + 1], cl = occL[xi], cr = occL[xi + 2];
+                const bool anch = a.anchor ? a.anchor[s] != 0 : false;
+                if (!a.field_only) for (int k = 0; k < K; ++k) {
+                    const uint32_t c = cellL[(xi + 1) * K + k];
+                    uint8_t code = EV_NONE;
+                    if (c != CELL_EMPTY)
+                        code = draw_proposal(M, anch, s, (c & CELL_PLUS) ? 1 : -1, (c & CELL_BOUND) != 0, fS, fW, beta, c0, cl, cr,
+                                             (uint32_t)step, (uint32_t)(step >> 32), c & CELL_ID, M.ens_base + e);
+                    propL[xi * K + k] = code;
+                }
+            } else {
+                for (int k = 0; k < K; ++k) propL[xi * K + k] = EV_NONE;
+            }
+        } else if (xi < TS) {
+            for (int k = 0; k < K; ++k) propL[xi * K + k] = EV_NONE;
+        }
+    }
+    __syncthreads();
+    TSTAMP(f_part)
+    if (a.field_only) return;                                  // flush of the pending deposits only (observation)
+    // ---------------------------------------------------------------- 3 + 4  exclusion, new cells of the owned sites, deposits
+    // number of proposers of frame site j (0 < j < nfr - 1) with an id below `id`: they sit on j - 1 (moving right) and j + 1 (moving left)
+    auto rank_at = [&](int j, uint32_t id) -> int {
+        int n = 0;
+        for (int k = 0; k < K; ++k) {
+            const uint32_t cl_ = cellL[j * K + k], cr_ = cellL[(j + 2) * K + k];
+            const int el = propL[(j - 1) * K + k] & 7, er = propL[(j + 1) * K + k] & 7;
+            n += (cl_ != CELL_EMPTY && (el == EV_RIGHT || el == EV_FWD) && (cl_ & CELL_ID) < id);
+            n += (cr_ != CELL_EMPTY && er == EV_LEFT && (cr_ & CELL_ID) < id);
+        }
+        return n;
+    };
+    auto cap_at = [&](int j) -> int { const int c = K - (int)occL[j + 1]; return c < 1 ? 1 : (c > 32 ? 32 : c); };
+    const size_t dep_base = ((size_t)e * a.ntile + tile) * a.dcap;
+    int my_spin = 0, my_live = 0;
+#pragma unroll
+    for (int r = 0; r < NOLD; ++r) {
+        const int xi = r * FU_THREADS + t;
+        if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
+        const int s = frame_site(xi);
+        uint32_t *out = a.cell_out + ((size_t)e * L + s) * K;
+        int n_out = 0;
+        for (int k = 0; k < K; ++k) {                          // the particles on this site: stay (possibly changed) or leave
+            uint32_t c = cellL[(xi + 1) * K + k];
+            if (c == CELL_EMPTY) continue;
+            const int ev = propL[xi * K + k] & 7, sgn = (c & CELL_PLUS) ? 1 : -1;
+            uint32_t d0 = 0, d1 = 0;
+            int nd = 0;
+            bool stays = true;
+            if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
+                const int j = ev == EV_LEFT ? xi - 1 : xi + 1;
+                if (rank_at(j, c & CELL_ID) < cap_at(j)) {
+                    stays = false;
+                    d0 = deposit(s, -1, -sgn); d1 = deposit(frame_site(j), 1, sgn); nd = 2;
+                }
+            } else if (ev == EV_BIND) c |= CELL_BOUND;
+            else if (ev == EV_UNBIND) c &= ~CELL_BOUND;
+            else if (ev == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
+            else if (ev == EV_EXIT) {
+                stays = false;
+                const unsigned kx = atomicAdd(&a.n_exit[e], 1u);
+                if ((int)kx < a.exit_cap) {
+                    double *row = a.exit_log + ((size_t)e * a.exit_cap + kx) * 3;
+                    row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
+                }
+                a.src[(size_t)e * a.Npad + a.slot_of[(size_t)e * a.N + (c & CELL_ID)]] =
+                    (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
+                d0 = deposit(s, -1, -sgn); nd = 1;
+            }
+            if (stays) { out[n_out++] = c; my_spin += (c & CELL_PLUS) ? 1 : -1; my_live += 1; }
+            if (nd && M.field_mode) {
+                const int kd = atomicAdd(&misc[0], nd);
+                if (kd + nd <= a.dcap) { a.dep_out[dep_base + kd] = d0; if (nd == 2) a.dep_out[dep_base + kd + 1] = d1; }
+            }
+        }
+        const int cap = cap_at(xi);
+        for (int k = 0; k < K; ++k) {                          // granted arrivals from the left and right neighbour
+            const uint32_t cl_ = cellL[xi * K + k], cr_ = cellL[(xi + 2) * K + k];
+            const int el = propL[(xi - 1) * K + k] & 7, er = propL[(xi + 1) * K + k] & 7;
+            if (cl_ != CELL_EMPTY && (el == EV_RIGHT || el == EV_FWD) && rank_at(xi, cl_ & CELL_ID) < cap) {
+                out[n_out++] = cl_; my_spin += (cl_ & CELL_PLUS) ? 1 : -1; my_live += 1;
+            }
+            if (cr_ != CELL_EMPTY && er == EV_LEFT && rank_at(xi, cr_ & CELL_ID) < cap) {
+                out[n_out++] = cr_; my_spin += (cr_ & CELL_PLUS) ? 1 : -1; my_live += 1;
+            }
+        }
+        for (int k = n_out; k < K; ++k) out[k] = CELL_EMPTY;
+    }
+    if (!M.field_mode) {
+        const long long s1 = wave_sum((long long)my_spin), s2 = wave_sum((long long)my_live);
+        if (lane == 0) { atomicAdd(&misc[1], (int)s1); atomicAdd(&misc[2], (int)s2); }
+    }
+    __syncthreads();
+    if (t == 0) {
+        a.dcnt_out[(size_t)e * a.ntile + tile] = (uint32_t)min(misc[0], a.dcap);
+        if (!M.field_mode) {
+            a.gpart_out[((size_t)e * a.ntile + tile) * 2] = misc[1];
+            a.gpart_out[((size_t)e * a.ntile + tile) * 2 + 1] = misc[2];
+        }
+    }
+#ifdef APS_STAMPS
+    TSTAMP(f_cnt)
+    if (t == 0 && a.stamps && blockIdx.x < 4096) {
+        unsigned long long *o = a.stamps + (size_t)blockIdx.x * 8;
+        o[0] = f_cnt; o[1] = f_stage; o[2] = f_copy; o[3] = f_proc; o[4] = __builtin_amdgcn_s_memtime() - f_start;
+        o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = r_start; o[7] = f_part;
+    }
+#endif
+}

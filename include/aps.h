@@ -59,10 +59,13 @@ typedef struct aps_params {
  *   LATTICE  the reference's own histogram -> smoothing -> gather, with the smoothed histograms
  *            tot_conv = W(x), s_conv = S(x) (ref :224-238) kept on the L sites and updated incrementally by the
  *            accepted events of each step; site occupancy (ref :248-252) likewise
- *   AUTO     LATTICE unless its per-bucket deposit lists would not fit (E*L*K*8 bytes > 16 GB) */
+ *   TILES    the LATTICE formulation with a site-centric state (one word per particle slot of a site) and the whole
+ *            step -- field update, rates, draws, exclusion, state update -- in ONE kernel over site tiles; same bits
+ *   AUTO     TILES for single-GPU handles, else LATTICE (PAIRS if the deposit lists would exceed 16 GB) */
 #define APS_METHOD_AUTO 0
 #define APS_METHOD_PAIRS 1
 #define APS_METHOD_LATTICE 2
+#define APS_METHOD_TILES 3
 
 int aps_device_count(void);
 const char *aps_last_error(const aps_handle *h);   /* h may be NULL: error of the last failed aps_create */
@@ -96,7 +99,7 @@ int aps_lattice_accumulate(aps_handle *h, int32_t ensemble, double *S, double *W
  * grid) and occ = occ_total (ref :248-252), each [L]; any pointer may be NULL.  LATTICE handles only. */
 int aps_get_lattice(aps_handle *h, int32_t ensemble, double *W, double *S, int32_t *occ);
 
-/* APS_METHOD_PAIRS or APS_METHOD_LATTICE: what AUTO resolved to. */
+/* APS_METHOD_PAIRS, _LATTICE or _TILES: what AUTO resolved to. */
 int aps_method(aps_handle *h);
 
 /* replaces the body of the `while t < T` loop (ref :511-516): nsteps synchronous steps of dt.
@@ -175,9 +178,9 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *la
  * on the handle's stream.  Event-bracketed durations of microsecond kernels carry this offset. */
 int aps_event_overhead(aps_handle *h, int32_t reps, double *ms_per_pair);
 
-/* The same for every kernel of the step: ms7[k] / launches7[k] summed over nsteps, k = pair_accumulate, propose,
- * claim, apply, plan_tiles, propose_lattice, field_update. */
-int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms7, int64_t *launches7);
+/* The same for every kernel of the step: ms8[k] / launches8[k] summed over nsteps, k = pair_accumulate, propose,
+ * claim, apply, plan_tiles, propose_lattice, field_update, tile_step. */
+int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms8, int64_t *launches8);
 
 #ifdef __cplusplus
 }

@@ -26,14 +26,14 @@ def capi():
     return mod
 
 
-@pytest.fixture(params=["pairs", "lattice"])
+@pytest.fixture(params=["pairs", "lattice", "tiles"])
 def method(request):
     return request.param
 
 
 def check_lattice(h, orc, ensemble=0):
     """The incrementally maintained lattice arrays equal the oracle's from-scratch recomputation, bit for bit."""
-    if h.method != "lattice":
+    if h.method not in ("lattice", "tiles"):
         return
     W, S, occ = h.get_lattice(ensemble)
     cp0, cm0, _ = orc.field_sites()
@@ -303,7 +303,7 @@ def test_full_size_properties(capi, method):
         orc.run(15)
         assert np.array_equal(pa, orc.pos) and np.array_equal(sa, orc.spin)
         check_lattice(a, orc)
-        if method == "lattice":                 # through the graph-replay path (>= 33 steps per call), field still exact
+        if method in ("lattice", "tiles"):      # through the graph-replay path (>= 33 steps per call), field still exact
             a.step(34)                          # (the oracle needs ~2 s per step at this size)
             b.step(34)
             orc.run(34)
@@ -386,6 +386,8 @@ def test_config5_scale_incremental_field_equals_from_scratch(capi):
 def test_two_rank_shards_emulated_on_one_gpu(capi, method):
     """world=2 on ONE device: each handle evaluates its own particle shard, the proposal blocks are swapped
     by hand (what the all-gather does), both commit everything -> identical states, equal to world=1."""
+    if method == "tiles":
+        pytest.skip("particle-index shards are a protocol of the particle-indexed formulations")
     torch = pytest.importorskip("torch")
     par = params(L=2000, K=2, sigma=0.02, anchor_positions=[0.5], anchor_radius=0.05, k_on=2.0, k_off=1.0, k_exit=0.5)
     rng = np.random.default_rng(21)
@@ -466,6 +468,8 @@ def test_hip_engine_over_nccl_world1(capi):
 def test_inlibrary_rccl_allgather_world1(capi, method):
     """aps_comm_init + aps_step with the library's own ncclAllGather (world size 1: the collective runs in place
     on one rank) must equal the plain single-GPU stepping."""
+    if method == "tiles":
+        pytest.skip("proposal all-gather belongs to the particle-indexed formulations")
     pytest.importorskip("torch")                          # as in production: torch's librccl is the process's RCCL
     par = params(L=1500, K=2, sigma=0.02)
     rng = np.random.default_rng(6)
