@@ -41,23 +41,28 @@ ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # SURVEY 8d (all-pairs): 4 B state read + 
 #   propose_lattice  N * (4 state + 4 index + 16 {W,S} + 12 occupancy + 1 proposal) + 4 L (site counters cleared)
 #   apply            N * (1 proposal + 4 state + 4 index) + C * (8 state/source word + 8 occupancy) + 4 D + 16 N / 64
 #   field_update     L * 32 ({W,S} read + write) + 4 D
-def lattice_algo_bytes(kernel, N, L, changed, deposits):
+#   tile_step        L * (32 {W,S} read + write  +  8 K cell words read + write) + 8 D (deposit written, read) + 8 T (counters)
+def step_algo_bytes(kernel, N, L, K, deposits):
+    changed = 0.6 * deposits          # estimate (a hop makes 2 deposits, a flip or an exit 1); only `apply` uses it
     return {"propose_lattice": 37.0 * N + 4.0 * L,
             "apply": 9.25 * N + 16.0 * changed + 4.0 * deposits,
-            "field_update": 32.0 * L + 4.0 * deposits}[kernel]
+            "field_update": 32.0 * L + 4.0 * deposits,
+            "tile_step": (32.0 + 8.0 * K) * L + 8.0 * deposits + 8.0 * L / 316.0}.get(kernel, 0.0)
 
 
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
 LDS_CYCLES_PER_64_PAIRS = 5.0  # measured (PMC 4.93): 4.5 per table gather (2.0 + 2.5 bank conflicts) + 0.5 source broadcast
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_lattice_pmc_traffic.json")   # rocprofv3 FETCH_SIZE/WRITE_SIZE of this command
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes, per workload
 
 
-def measured_traffic_bytes(kernel="pair_accumulate"):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (bench.py
-    cannot collect PMC itself).  None if the summary is missing."""
+def measured_traffic_bytes(workload, kernel):
+    """HBM-side bytes per launch of `kernel` in `workload` from the committed rocprofv3 --pmc passes of this round's
+    binary (bench.py cannot collect PMC itself; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    streaming reads is NOT applied: these kernels read 4-16 bytes per lane).  None when no pass was recorded for this
+    workload and kernel -- never another workload's number."""
     try:
         with open(TRAFFIC_FILE) as fh:
-            d = json.load(fh)["per_dispatch"][kernel]
+            d = json.load(fh)["workloads"][workload][kernel]
         return (d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0
     except Exception:
         return None
@@ -273,7 +278,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "pde", "gillespie"] + sorted(EXTRA))
-    ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs"])
+    ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs", "tiles"])
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K steps; the line reports their median")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -295,7 +301,7 @@ def main():
     if capi.device_count() < 1:
         raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
     pos, spin = initial_state(w)
-    roof, comm_path = None, ""
+    roof, comm_path, extra = None, "", {}
     sharded_path = world > 1 or os.environ.get("APS_BENCH_FORCE_SHARDED") == "1"   # the switch lets one rank rehearse it
     if sharded_path:
         import torch
@@ -384,13 +390,17 @@ def main():
                     h.commit()
                 torch.cuda.synchronize()
         run(args.warmup)
-        dist.barrier()
-        t0 = time.perf_counter()
-        run(args.steps)                                      # returns after the stream has drained
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-        dist.barrier()
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+        times = []
+        for _ in range(max(1, args.repeats)):                # each repeat: barrier, K steps, drain, barrier; MAX over ranks
+            dist.barrier()
+            t0 = time.perf_counter()
+            run(args.steps)                                  # returns after the stream has drained
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.barrier()
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            times.append(float(el.item()))
+        elapsed = float(np.median(times))
+        extra = {"repeats": len(times), "repeats_ms_per_step": [t / args.steps * 1e3 for t in times], "graph_replay": False}
         # every rank must hold the same state; compare a checksum
         p, s, b, a = h.get_state()
         chk = torch.tensor([int(p.astype(np.int64).sum()), int((s > 0).sum())], dtype=torch.int64)
@@ -404,9 +414,16 @@ def main():
         for e in range(n_ens):
             h.set_state(pos, spin, ensemble=e)
         h.step(args.warmup)                       # aps_step synchronises its stream before returning
-        t0 = time.perf_counter()
-        h.step(args.steps)
-        elapsed = time.perf_counter() - t0
+        times = []
+        for _ in range(max(1, args.repeats)):     # median of >= 5 repeats of the K timed steps
+            t0 = time.perf_counter()
+            h.step(args.steps)
+            times.append(time.perf_counter() - t0)
+        graph_steps, single_steps = h.step_info()
+        elapsed = float(np.median(times))
+        extra = {"repeats": len(times), "repeats_ms_per_step": [t / args.steps * 1e3 for t in times],
+                 "graph_replay": single_steps == 0, "steps_from_graphs": graph_steps, "steps_launched_singly": single_steps}
+        hbm_copy = h.copy_bandwidth(1 << 30, 5)   # this box's streaming ceiling (read + written bytes of a 1 GiB copy)
         # per-kernel durations, timed live with HIP events on the stream the kernels are launched on
         reps = max(10, min(args.steps, 50))
         if h.method == "pairs":
@@ -415,8 +432,9 @@ def main():
             achieved = ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens / avg_s / 1e9
             pairs_per_s = pairs / (ms * 1e-3)
             lds_peak_pairs = 256 * 2.4e9 / LDS_CYCLES_PER_64_PAIRS * 64      # one LDS pipe per CU
-            roof = {"bound": "hbm", "kernel": "pair_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
+            roof = {"bound": "hbm", "bound_measured": "lds (table gather; PMC in profiles/r01_pmc_traffic.json)",
+                    "kernel": "pair_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(args.workload, "pair_accumulate"),
                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * w["N"] * n_ens,
                     "note": "the contract's HBM figure; this kernel is bound by the LDS table gather (the 0.4 MB state "
                             "lives in L2), see on_chip",
@@ -425,36 +443,40 @@ def main():
                                 "lds_cycles_per_64_pairs": LDS_CYCLES_PER_64_PAIRS,
                                 "valu_issue_slots_per_pair": 4, "valu_frac": pairs_per_s * 4 / VALU_LANE_OPS_PER_S}}
         else:
-            before = h.get_state()
-            ms_fu, n_fu, deposits = h.step_timed(reps)            # deposits = field changes of the sampled steps
-            after = h.get_state()
+            ms_fu, n_fu, deposits = h.step_timed(reps)            # deposits = field changes of the sampled steps (device counters)
             prof = h.step_profile(reps)
-            # seconds per launch: start/stop events attached to each kernel's own dispatch (hipExtLaunchKernelGGL), i.e.
+            # seconds per launch: start/stop events attached to each kernel's own dispatch (hipExtLaunchKernel), i.e.
             # the begin -> end interval rocprofv3 --kernel-trace reports.  APS_PROF_BRACKET=1 switches to events recorded
             # around the launch instead, which read ~2 us more per kernel (the event packets' own cost).
             kern = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}
             bracketed = os.environ.get("APS_PROF_BRACKET") is not None
             dep_per_step = deposits / max(n_fu, 1)
-            changed_per_step = 0.6 * dep_per_step                 # a hop makes 2 deposits, a flip 1 (about half each)
             N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
-            algo = {k: lattice_algo_bytes(k, N_all, L_all, changed_per_step, dep_per_step) for k in kern}
+            algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step) for k in kern}
             dom = max(kern, key=kern.get)
             achieved = algo[dom] / kern[dom] / 1e9
             step_bytes = sum(algo.values())
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(dom),
+            us_step = elapsed / args.steps * 1e6
+            # what limits the kernel: HBM only if the algorithmic bytes move at a sizeable fraction of the measured copy rate
+            if achieved >= 0.5 * hbm_copy:
+                limiter = "hbm"
+            elif L_all * (32 + 8 * w["K"]) < 200e6:
+                limiter = "latency (cache-resident working set: dependent load -> compute -> store chain of a ~10 us launch)"
+            else:
+                limiter = "valu/lds issue of the deposit sweep (f64 fma + LDS table gather per deposit x 64-site row)"
+            roof = {"bound": "hbm", "bound_measured": limiter, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(args.workload, dom),
+                    "hbm_copy_GBps": hbm_copy, "frac_of_copy": achieved / hbm_copy,
                     "avg_launch_us": kern[dom] * 1e6, "algorithmic_bytes_per_launch": algo[dom],
                     "timing": "HIP events around each launch" if bracketed else "HIP start/stop events attached to each dispatch",
                     "per_kernel": {k: {"avg_launch_us": kern[k] * 1e6, "algorithmic_bytes_per_launch": algo[k],
-                                       "achieved_GBps": algo[k] / kern[k] / 1e9, "traffic": measured_traffic_bytes(k)} for k in kern},
-                    "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step_graph_replay": elapsed / args.steps * 1e6,
-                                   "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
-                                   "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
-                    "deposits_per_step": dep_per_step,
-                    "note": "lattice formulation: three short kernels per step replayed from a hipGraph; the per-kernel "
-                            "durations come from a run launched kernel by kernel with HIP events on the launch stream; the working set (12 MB) "
-                            "is cache resident, so the kernels are latency / launch-boundary bound, not HBM bound"}
-            del before, after
+                                       "achieved_GBps": algo[k] / kern[k] / 1e9,
+                                       "traffic": measured_traffic_bytes(args.workload, k)} for k in kern},
+                    "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step": us_step,
+                                   "achieved_GBps": step_bytes / (us_step * 1e-6) / 1e9,
+                                   "frac": step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                    "deposits_per_step": dep_per_step, "kernels_per_step": len(kern)}
+        roof = dict(roof or {}, **{"hbm_copy_GBps": hbm_copy})
     p, s, b, a = h.get_state()
     assert a.all() and np.bincount(p, minlength=w["L"]).max() <= w["K"]
     h_method = h.method
@@ -474,6 +496,7 @@ def main():
     }
     if sharded_path:
         out["exchange"], out["ranks_seen"] = exchange, ranks_seen
+    out.update(extra)
     if roof:
         out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline and args.workload == "config2":

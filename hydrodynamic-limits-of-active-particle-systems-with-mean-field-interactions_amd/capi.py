@@ -101,6 +101,8 @@ def load():
         "aps_resort": (C.c_int, [vp]),
         "aps_step_timed": (C.c_int, [vp, i64, P(dbl), P(i64), P(dbl)]),
         "aps_step_profile": (C.c_int, [vp, i64, vp, vp]),
+        "aps_step_info": (C.c_int, [vp, P(i64), P(i64)]),
+        "aps_copy_bandwidth": (C.c_int, [vp, i64, i32, P(dbl)]),
         "aps_lattice_accumulate": (C.c_int, [vp, i32, vp, vp, vp, i64]),
         "aps_get_lattice": (C.c_int, [vp, i32, vp, vp, vp]),
         "aps_method": (C.c_int, [vp]),
@@ -247,6 +249,18 @@ class Handle:
         ms, cnt = np.zeros(len(KERNELS)), np.zeros(len(KERNELS), np.int64)
         self._ck(self.lib.aps_step_profile(self._h, int(nsteps), _ptr(ms), _ptr(cnt)))
         return {k: (float(m), int(c)) for k, m, c in zip(KERNELS, ms, cnt)}
+
+    def step_info(self):
+        """(steps replayed from hipGraphs, steps launched kernel by kernel) of the last step() call."""
+        g, k = C.c_int64(), C.c_int64()
+        self._ck(self.lib.aps_step_info(self._h, C.byref(g), C.byref(k)))
+        return g.value, k.value
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=5):
+        """GB/s (read + written) of a plain streaming copy kernel on this handle's device."""
+        r = C.c_double()
+        self._ck(self.lib.aps_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(r)))
+        return r.value
 
     def event_overhead(self, reps=50):
         """Elapsed time (ms) the HIP events report for an empty bracket on the handle's stream."""

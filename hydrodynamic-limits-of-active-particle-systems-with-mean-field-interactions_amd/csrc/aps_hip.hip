@@ -335,14 +335,10 @@ __host__ __device__ inline size_t lds_total_bytes(int tlen, bool tab_lds) { retu
 
 // Epilogue shared by both formulations: m = clip(S/W) -> rates (ref :261-351) -> Philox draw -> proposal byte
 // (event code | (free capacity of the hop target - 1) << 3).  c0/cl/cr = occupancy of the own / left / right site.
-__device__ inline uint8_t draw_proposal(const Model &M, bool anch, int p, int spin, bool bound, double accS, double accW,
-                                        double beta, int c0, int cl, int cr, uint32_t step_lo, uint32_t step_hi,
-                                        uint32_t orig, int ens) {
-    double mloc = 0.0;
-    if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+// The draw itself: x = Philox4x32-10 output of (step, particle id, ensemble) under the handle's key.
+__device__ inline uint8_t decide_proposal(const Model &M, bool anch, int p, int spin, bool bound, double mloc, double beta,
+                                          int c0, int cl, int cr, const uint32_t (&x)[4]) {
     const Channels c = channels(M, anch, p, spin, bound, mloc, beta, c0, cl, cr);
-    uint32_t x[4];
-    philox4x32_10(step_lo, step_hi, orig, (uint32_t)ens, M.seed_lo, M.seed_hi, x);
     const double u0 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6)) * 0x1.0p-53;
     const double u1 = (double)x[2] * 0x1.0p-32, u2 = (double)x[3] * 0x1.0p-32;
     const double p_fire = 1.0 - aps_exp(-(c.total * M.dt));
@@ -364,6 +360,20 @@ __device__ inline uint8_t draw_proposal(const Model &M, bool anch, int p, int sp
     int cap = M.K - occ_t;                                   // free capacity of the hop target at step start
     cap = cap < 1 ? 1 : (cap > 32 ? 32 : cap);
     return (uint8_t)(ev | ((cap - 1) << 3));
+}
+
+__device__ inline double clip_field(double accS, double accW) {
+    double mloc = 0.0;
+    if (accW > 0.0) { mloc = accS / accW; mloc = mloc > 1.0 ? 1.0 : (mloc < -1.0 ? -1.0 : mloc); }
+    return mloc;
+}
+
+__device__ inline uint8_t draw_proposal(const Model &M, bool anch, int p, int spin, bool bound, double accS, double accW,
+                                        double beta, int c0, int cl, int cr, uint32_t step_lo, uint32_t step_hi,
+                                        uint32_t orig, int ens) {
+    uint32_t x[4];
+    philox4x32_10(step_lo, step_hi, orig, (uint32_t)ens, M.seed_lo, M.seed_hi, x);
+    return decide_proposal(M, anch, p, spin, bound, clip_field(accS, accW), beta, c0, cl, cr, x);
 }
 
 // plan<BC>: one wave per target group (RT consecutive tiles) lists the source tiles that can matter (tile index
@@ -1172,6 +1182,12 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
 
 #include "tile_step.hpp"
 
+// streaming copy, 16 bytes per lane: the HBM ceiling this box reaches in practice (bench.py quotes it beside the 8 TB/s spec)
+__global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 // ---- site-centric state <-> particle-indexed arrays (observation, hooks, upload of the tiles method)
 // cells -> src (live particles only: an exit wrote its own record), occupancy per site
 __global__ __launch_bounds__(256) void cells_to_slots(const uint32_t *__restrict__ cell, const uint32_t *__restrict__ slot_of,
@@ -1279,8 +1295,9 @@ struct aps_handle {
     bool fu_table_in_lds = true;
     bool field_dirty = true;
     hipStream_t cap_stream = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    int graph_steps = 0;
+    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // captured runs of GRAPH_SIZES[k] steps
+    bool graphs_built = false;
+    int64_t last_graph_steps = 0, last_single_steps = 0;      // how the last aps_step call was executed
     // tiles formulation (site-centric state, one kernel per step): everything double buffered by step parity
     double2 *d_wsb[2] = {nullptr, nullptr};
     uint32_t *d_cell[2] = {nullptr, nullptr}, *d_tdcnt[2] = {nullptr, nullptr}, *d_tdep[2] = {nullptr, nullptr};
@@ -1314,6 +1331,7 @@ namespace {
     } while (0)
 
 int fail(aps_handle *h, int code, const std::string &msg) { h->err = msg; return code; }
+void drop_graphs(aps_handle *h);
 
 // RCCL is resolved at run time (no link dependency; reuses the copy the process already loaded, e.g. PyTorch's)
 struct Rccl {
@@ -1722,7 +1740,6 @@ int flush_field(aps_handle *h) {
         if (rc) return rc;
     }
     HIP_TRY(h, hipMemsetAsync(h->d_tdcnt[cur], 0, (size_t)h->E * h->ts_ntile * 4, h->stream));
-    if (h->gexec) { /* captured kernels read the same buffers: nothing to rebuild */ }
     h->field_pending = false;
     return APS_OK;
 }
@@ -1982,7 +1999,7 @@ void aps_destroy(aps_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    drop_graphs(h);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
     for (int b = 0; b < 2; ++b)
@@ -2112,31 +2129,41 @@ int aps_commit(aps_handle *h) {
 
 namespace {
 
-constexpr int GRAPH_STEPS = 32;       // steps per captured graph (even: the kernels' parity arguments are baked in)
+constexpr int GRAPH_SIZES[3] = {32, 8, 2};   // steps per captured graph (even: the kernels' parity arguments are baked in)
 
-// Lattice steps are a few microseconds of GPU time each, less than the host needs to launch their kernels
-// one by one: GRAPH_STEPS steps are captured once (the step index lives in device memory, see stepw) and replayed.
-int build_graph(aps_handle *h) {
-    if (h->gexec) return APS_OK;
+// Lattice / tile steps are a few microseconds of GPU time each, less than the host needs to launch their kernels
+// one by one: runs of 32, 8 and 2 steps are captured once (the step index lives in device memory, see stepw) and any
+// step count is replayed as a sum of those.
+int build_graphs(aps_handle *h) {
+    if (h->graphs_built) return APS_OK;
     if (!h->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-    const hipStream_t user_stream = h->stream;
-    const int64_t step0 = h->step;
-    HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    h->stream = h->cap_stream;
-    h->step = 0;                                             // only the parity is baked in: replays start on even steps
-    int rc = APS_OK;
-    for (int k = 0; k < GRAPH_STEPS && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
-    h->stream = user_stream;
-    h->step = step0;
-    hipGraph_t graph = nullptr;
-    const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-    const hipError_t ie = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) { h->gexec = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-    h->graph_steps = GRAPH_STEPS;
+    const bool dirty = h->slots_dirty, pending = h->field_pending;
+    for (int g = 0; g < 3; ++g) {
+        const hipStream_t user_stream = h->stream;
+        const int64_t step0 = h->step;
+        HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        h->stream = h->cap_stream;
+        h->step = 0;                                         // only the parity is baked in: replays start on even steps
+        int rc = APS_OK;
+        for (int k = 0; k < GRAPH_SIZES[g] && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
+        h->stream = user_stream;
+        h->step = step0;
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&h->gexec[g], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { h->gexec[g] = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    }
+    h->slots_dirty = dirty; h->field_pending = pending;      // capturing launched nothing
+    h->graphs_built = true;
     return APS_OK;
+}
+
+void drop_graphs(aps_handle *h) {
+    for (int g = 0; g < 3; ++g) if (h->gexec[g]) { (void)hipGraphExecDestroy(h->gexec[g]); h->gexec[g] = nullptr; }
+    h->graphs_built = false;
 }
 
 int one_step(aps_handle *h) {
@@ -2213,18 +2240,51 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     if (rc) return rc;
     int64_t s = 0;
     static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
-    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps > 0) {
-        if ((rc = build_graph(h))) return rc;                              // once per handle, on the first stepping call
-        if ((h->step & 1) && nsteps - s > h->graph_steps) { if ((rc = one_step(h))) return rc; ++s; }   // replays start on even steps
-        for (; !(h->step & 1) && nsteps - s >= h->graph_steps; s += h->graph_steps) {
-            HIP_TRY(h, hipGraphLaunch(h->gexec, h->stream));
-            h->step += h->graph_steps;
-            if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; }
-        }
+    h->last_graph_steps = h->last_single_steps = 0;
+    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps >= GRAPH_SIZES[2]) {
+        if ((rc = build_graphs(h))) return rc;                             // once per handle, on the first stepping call
+        if ((h->step & 1) && nsteps - s > 0) { if ((rc = one_step(h))) return rc; ++s; ++h->last_single_steps; }   // replays start on even steps
+        for (int g = 0; g < 3; ++g)
+            for (; nsteps - s >= GRAPH_SIZES[g]; s += GRAPH_SIZES[g]) {
+                HIP_TRY(h, hipGraphLaunch(h->gexec[g], h->stream));
+                h->step += GRAPH_SIZES[g];
+                h->last_graph_steps += GRAPH_SIZES[g];
+                if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; }
+            }
     }
-    for (; s < nsteps; ++s)
+    for (; s < nsteps; ++s, ++h->last_single_steps)
         if ((rc = one_step(h))) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps) {
+    if (!h) return APS_ERR_ARG;
+    if (graph_steps) *graph_steps = h->last_graph_steps;
+    if (single_steps) *single_steps = h->last_single_steps;
+    return APS_OK;
+}
+
+int aps_copy_bandwidth(aps_handle *h, int64_t nbytes, int32_t reps, double *gbytes_per_s) {
+    if (!h || !gbytes_per_s || nbytes < (1 << 20) || reps < 1) return APS_ERR_ARG;
+    const size_t n16 = (size_t)nbytes / 16;
+    uint4 *a = nullptr, *b = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&a), n16 * 16));
+    if (hipMalloc(reinterpret_cast<void **>(&b), n16 * 16) != hipSuccess) { (void)hipFree(a); return fail(h, APS_ERR_HIP, "aps_copy_bandwidth: out of device memory"); }
+    (void)hipMemsetAsync(a, 1, n16 * 16, h->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)h->num_cu * 32);
+    hipLaunchKernelGGL(copy16, dim3(blocks), dim3(256), 0, h->stream, a, b, n16);        // warm-up
+    (void)hipEventRecord(e0, h->stream);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16, dim3(blocks), dim3(256), 0, h->stream, a, b, n16);
+    (void)hipEventRecord(e1, h->stream);
+    const hipError_t se = hipStreamSynchronize(h->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+    if (se != hipSuccess || !(ms > 0.f)) return fail(h, APS_ERR_HIP, "aps_copy_bandwidth: copy kernel failed");
+    *gbytes_per_s = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;                // bytes read + bytes written
     return APS_OK;
 }
 
@@ -2456,7 +2516,7 @@ int aps_exchange_buffer(aps_handle *h, void **dev_ptr, int64_t *total_bytes, int
 
 int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes) {
     if (!h) return APS_ERR_ARG;
-    if (h->gexec) { (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // captured kernels hold the old pointer
+    if (h->graphs_built) { (void)hipStreamSynchronize(h->stream); drop_graphs(h); }   // captured kernels hold the old pointer
     if (!dev_ptr) { h->d_prop = h->d_prop_own; return APS_OK; }
     if (nbytes < (int64_t)h->E * h->SH * h->world) return fail(h, APS_ERR_ARG, "aps_bind_exchange_buffer: buffer too small");
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -47,27 +47,73 @@ template <bool TAB_LDS> struct TsGeom { static constexpr int SB = TAB_LDS ? 4 : 
 
 __host__ __device__ inline int ts_table_pad(int RS, int own) { return 64 * RS + own + 2; }
 __host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TsGeom<false>::GB * own) + 64 * RS + 8 + 127) / 128 * 128; }
-struct TsLds { size_t seg, cells, props, occ, misc, tab, total; };
+constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
+struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
 __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K) {
     TsLds l;
     const size_t TS = 64 * (size_t)RS;
+    const int ncell = (int)(TS + 2) * K;
+    l.Q = (ncell + FU_WAVES - 1) / FU_WAVES;                     // cells per wave
+    l.cells_in_regs = l.Q <= 64 * TS_CREG;
     l.seg = 0;
-    l.cells = l.seg + (size_t)FU_WAVES * 2 * ((tab_lds ? FU_SEG : FU_SEG_WIN) + 4) * sizeof(uint32_t);
+    l.cells = l.seg + (size_t)FU_WAVES * 4 * (TS_SEG + 4) * sizeof(uint32_t);
     l.props = l.cells + ((TS + 2) * K * 4 + 7) / 8 * 8;
     l.occ = l.props + (TS * K + 7) / 8 * 8;
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
-    l.tab = l.misc + 64;
+    l.plist = l.misc + 64;
+    l.tab = l.plist + (l.cells_in_regs ? (size_t)FU_WAVES * l.Q * 8 : 0);
     const size_t table = tab_lds ? ((size_t)tlen + 2 + ts_table_pad(RS, own)) / 2 * 2 * sizeof(double)
                                  : (size_t)2 * ts_win_entries(RS, own) * sizeof(double);
     const size_t red = (size_t)FU_WAVES * TS * sizeof(double2);
-    l.total = l.tab + (table > red ? table : red);
+    l.field = l.tab + red;                                      // fresh {W, S} of the frame sites, behind the partial sums
+    const size_t after = red + TS * sizeof(double2);
+    l.total = l.tab + (table > after ? table : after);
     return l;
+}
+
+// weights of four wave-uniform deposits at this lane's RS sites.  VAR 0: interior (padded LDS table or window: no clamp),
+// VAR 1: torus
+template <int VAR, bool TAB_LDS, int RS>
+__device__ __forceinline__ void ts_weights(const uint32_t (&ent)[4], const uint32_t (&x8)[RS], const uint32_t tbase,
+                                           const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8, double (&w)[4][RS]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t p8 = (ent[k] & POS_MASK) << 3;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (VAR == 0) {
+                const uint32_t d = sad3(x8[r], p8, tbase);
+                w[k][r] = table_at<TAB_LDS>(table_g, TAB_LDS ? d : min(d, tlen8));
+            } else {
+                const uint32_t d8 = sad3(x8[r], p8, 0u);
+                w[k][r] = table_at<TAB_LDS>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
+            }
+        }
+    }
+}
+
+// four deposits of ONE class into ONE accumulator set: a deposit's (cW, cS) is (c, c) [class P: a plus particle came or
+// went], (c, -c) [class M: a minus particle] or (0, c) [class F: a flip], so one fma per table read does it.
+// MODE 0: coefficient = cW (classes P, M), MODE 1: coefficient = cS (class F).  W = P + M, S = P - M + F, all exact.
+template <int VAR, bool TAB_LDS, int RS, int MODE>
+__device__ __forceinline__ void ts_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase, const double *__restrict__ table_g,
+                                         const uint32_t tlen8, const uint32_t L8, double (&acc)[RS]) {
+    const uint32_t ent[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
+    double w[4][RS];
+    ts_weights<VAR, TAB_LDS, RS>(ent, x8, tbase, table_g, tlen8, L8, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double c = MODE == 0 ? (double)((int)((ent[k] >> 27) & 3u) - 1) : (double)((int)(ent[k] >> 29) - 2);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) acc[r] = fma(w[k][r], c, acc[r]);
+    }
 }
 
 template <int BC, bool TAB_LDS, int RS>
 __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const double *__restrict__ table_g) {
     constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS;
-    constexpr int SEG = TAB_LDS ? FU_SEG : FU_SEG_WIN;
+    constexpr int SEG = TS_SEG;
     constexpr int SB = TsGeom<TAB_LDS>::SB, NSLOT = TsGeom<TAB_LDS>::NSLOT, GB = TsGeom<TAB_LDS>::GB;
     extern __shared__ double lds[];
     const Model &M = a.m;
@@ -75,20 +121,23 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K);
     char *lds_c = reinterpret_cast<char *>(lds);
     uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
-    uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame sites -1 .. TS
+    uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
     uint8_t *propL = reinterpret_cast<uint8_t *>(lds_c + lay.props);         // [TS K]
     uint8_t *occL = reinterpret_cast<uint8_t *>(lds_c + lay.occ);            // [TS + 2]
-    int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // [0] deposits of this tile, [1] spin sum, [2] live count
+    int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // 0 deposits of this tile, 1 spin sum, 2 live count, 4/5 global sums
     double *tab = reinterpret_cast<double *>(lds_c + lay.tab);
     double2 *red = reinterpret_cast<double2 *>(tab);
+    double2 *fieldL = reinterpret_cast<double2 *>(lds_c + lay.field);        // [TS]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
-    uint32_t *seg = seg_all + wave * 2 * (SEG + 4), *segi = seg + SEG + 4;
+    uint32_t *segP = seg_all + wave * 4 * (SEG + 4), *segM = segP + SEG + 4, *segF = segM + SEG + 4, *segI = segF + SEG + 4;
+    uint2 *plist = reinterpret_cast<uint2 *>(lds_c + lay.plist) + (size_t)wave * lay.Q;   // this wave's particles {pos | k << 16, cell}
     const int tile = a.tile_lo + (int)blockIdx.x;
     const int own0 = tile * OWN, own_n = min(OWN, L - own0), nfr = own_n + 4;   // owned sites, valid frame positions
     const int x0 = own0 - 2;                                   // site of frame position 0 (may lie outside the lattice)
     const int x0c = max(x0, 0), x1c = min(x0 + TS - 1, L - 1); // the frame clipped to the lattice (range tests)
     const int Rt = a.tlen - 1;
     const unsigned long long step = a.stepw[a.par];
+    const double beta = a.beta[e];
     if (blockIdx.x == 0 && e == 0 && t == 0 && !a.field_only) a.stepw[a.par ^ 1] = step + 1ull;   // nobody reads that word during this step
     // site of frame position i (position -1 .. TS); -1 = no such site (beyond a wall, or beyond the valid frame)
     auto frame_site = [&](int i) -> int {
@@ -105,16 +154,21 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
 #define TSTAMP(var)
 #endif
     // ---------------------------------------------------------------- requests that depend on nothing
-    // cells of the frame (+1 site either side) through registers when they fit, else by a plain loop
-    const int ncell = (TS + 2) * K;
+    // The cells of the frame (+1 site either side), a contiguous chunk of Q cells per wave.  When a chunk fits the
+    // wave's registers the wave compacts ITS particles right away (ballot + mbcnt, no barrier) and draws their Philox
+    // numbers while the table and the deposit lists are still on their way.
+    const int ncell = (TS + 2) * K, Q = lay.Q;
+    const int c_lo = wave * Q, c_hi = min(c_lo + Q, ncell);
     uint32_t creg[TS_CREG];
-    const bool cells_in_regs = ncell <= TS_CREG * FU_THREADS;
-    if (cells_in_regs) {
+    int cpk[TS_CREG];
+    if (lay.cells_in_regs) {
 #pragma unroll
         for (int u = 0; u < TS_CREG; ++u) {
-            const int c = t + u * FU_THREADS;
-            const int s = c < ncell ? frame_site(c / K - 1) : -1;
-            creg[u] = s >= 0 ? a.cell_in[((size_t)e * L + s) * K + c % K] : CELL_EMPTY;
+            const int c = c_lo + lane + 64 * u;
+            const int pos = K == 1 ? c - 1 : c / K - 1, k = K == 1 ? 0 : c - (pos + 1) * K;
+            const int s = c < c_hi ? frame_site(pos) : -1;
+            creg[u] = s >= 0 ? a.cell_in[((size_t)e * L + s) * K + k] : CELL_EMPTY;
+            cpk[u] = (pos >= 0 && pos < nfr) ? (pos | (k << 16)) : -1;
         }
     } else {
         for (int c = t; c < ncell; c += FU_THREADS) {
@@ -170,9 +224,25 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         for (int i = t; i < a.ntile; i += FU_THREADS) { gS += a.gpart_in[((size_t)e * a.ntile + i) * 2]; gN += a.gpart_in[((size_t)e * a.ntile + i) * 2 + 1]; }
     }
     if (t < 8) misc[t] = 0;
-    if (cells_in_regs) {
+    for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;   // EV_NONE everywhere
+    // this wave's particles (needs only the cell loads, the oldest requests) and their random numbers
+    int n_w = 0;
+    uint2 mine = make_uint2(0u, CELL_EMPTY);
+    uint32_t rx[4] = {0u, 0u, 0u, 0u};
+    if (lay.cells_in_regs) {
 #pragma unroll
-        for (int u = 0; u < TS_CREG; ++u) { const int c = t + u * FU_THREADS; if (c < ncell) cellL[c] = creg[u]; }
+        for (int u = 0; u < TS_CREG; ++u) {
+            const bool occ = creg[u] != CELL_EMPTY && cpk[u] >= 0;
+            const unsigned long long mm = __ballot(occ);
+            if (occ) plist[n_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)cpk[u], creg[u]);
+            n_w += __popcll(mm);
+        }
+        if (!a.field_only && lane < n_w) {
+            mine = plist[lane];
+            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, rx);
+        }
+#pragma unroll
+        for (int u = 0; u < TS_CREG; ++u) { const int c = c_lo + lane + 64 * u; if (c < c_hi) cellL[c] = creg[u]; }
     }
     const int tpad = TAB_LDS ? a.tlen + ts_table_pad(RS, OWN) : 0;
     uint32_t tbase = 0;
@@ -185,12 +255,12 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     }
     const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)L << 3;
     uint32_t x8[RS];
-    double accW[RS], accS[RS];
+    double accP[RS], accM[RS], accF[RS], accWi[RS], accSi[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         int s = x0 + r * 64 + lane;
         if (BC == 1) { s %= L; if (s < 0) s += L; } else s = min(max(s, 0), L - 1);
-        x8[r] = (uint32_t)s << 3; accW[r] = accS[r] = 0.0;
+        x8[r] = (uint32_t)s << 3; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0.0;
     }
     __syncthreads();                                           // table and cells staged
     TSTAMP(f_stage)
@@ -218,24 +288,30 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         dmin_next = dmin;
         null_next = min(max(x0c, sA), sB);
     };
-    int nseg = 0, nimg = 0;
-    const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg), *segi4 = reinterpret_cast<const uint4 *>(segi);
-    auto flush = [&]() {
-        if (lane < 4) { seg[nseg + lane] = DEP_NULL | (uint32_t)null_site; segi[nimg + lane] = DEP_NULL | (uint32_t)x0c; }
-        const int n4 = (nseg + 3) >> 2, ni4 = (nimg + 3) >> 2;
-#pragma unroll 1
-        for (int i = 0; i < n4; ++i) {
-            const uint4 q = seg4[i];
-            if (BC == 1) fu_group<1, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
-            else if (!TAB_LDS && windowed) fu_group<0, true, RS>(q, x8, win_base, table_g, tlen8, L8, accW, accS);
-            else fu_group<0, TAB_LDS, RS>(q, x8, tbase, table_g, tlen8, L8, accW, accS);
+    int nP = 0, nM = 0, nF = 0, nI = 0;                        // entries waiting in this wave's four segments
+    const uint4 *segP4 = reinterpret_cast<const uint4 *>(segP), *segM4 = reinterpret_cast<const uint4 *>(segM),
+                *segF4 = reinterpret_cast<const uint4 *>(segF), *segI4 = reinterpret_cast<const uint4 *>(segI);
+    auto flush = [&]() {                                       // sweep the frame with the segments' deposits, class by class
+        if (lane < 4) {
+            const uint32_t pad = DEP_NULL | (uint32_t)null_site;   // a site whose distances stay in table range, coefficients 0
+            segP[nP + lane] = pad; segM[nM + lane] = pad; segF[nF + lane] = pad; segI[nI + lane] = DEP_NULL | (uint32_t)x0c;
         }
+#define TS_SWEEP(SEG4, N, MODE, ACC) \
+        _Pragma("unroll 1") for (int i = 0; i < ((N) + 3) >> 2; ++i) { \
+            const uint4 q = SEG4[i]; \
+            if (BC == 1) ts_group<1, TAB_LDS, RS, MODE>(q, x8, tbase, table_g, tlen8, L8, ACC); \
+            else if (!TAB_LDS && windowed) ts_group<0, true, RS, MODE>(q, x8, win_base, table_g, tlen8, L8, ACC); \
+            else ts_group<0, TAB_LDS, RS, MODE>(q, x8, tbase, table_g, tlen8, L8, ACC); }
+        TS_SWEEP(segP4, nP, 0, accP)
+        TS_SWEEP(segM4, nM, 0, accM)
+        TS_SWEEP(segF4, nF, 1, accF)
+#undef TS_SWEEP
 #pragma unroll 1
-        for (int i = 0; i < ni4; ++i) fu_group<2, TAB_LDS, RS>(segi4[i], x8, tbase, table_g, tlen8, L8, accW, accS);
+        for (int i = 0; i < (nI + 3) >> 2; ++i) fu_group<2, TAB_LDS, RS>(segI4[i], x8, tbase, table_g, tlen8, L8, accWi, accSi);
 #ifdef APS_STAMPS
-        f_n += nseg + nimg;
+        f_n += nP + nM + nF + nI;
 #endif
-        nseg = nimg = 0;
+        nP = nM = nF = nI = 0;
     };
     const int ngroups = (nbk + GB - 1) / GB;
     if (!TAB_LDS && windowed && ngroups > 0) stage(0);
@@ -273,15 +349,20 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             nx_ent = (ok1 && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b1) * a.dcap + slot] : DEP_NULL;
         }
         cnt = min(cnt, (uint32_t)a.dcap);
+        // NSLOT slots of each of the wave's buckets: compact the valid ones into the wave's segments by class.  Near a
+        // reflecting wall the deposits with an image in reach go to the (untyped) image segment.
+#define TS_PUT(SEGX, NX, COND) { const unsigned long long m_ = __ballot(COND); \
+            if (COND) SEGX[NX + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u))] = en_; \
+            NX += __popcll(m_); }
 #define TS_ROUND(EN, K0) { \
+            const uint32_t en_ = (EN); \
             const bool valid = (K0) + slot < cnt; \
-            const int dp = (int)((EN) & POS_MASK); \
+            const int dp = (int)(en_ & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2; \
             const bool img = valid && wall && ((x0c + dp + 1 <= Rt) || (2 * L - 1 - x1c - dp <= Rt)); \
-            const unsigned long long mm = __ballot(valid && !img), mi = __ballot(img); \
-            if (nseg + 64 > SEG || nimg + 64 > SEG) flush(); \
-            if (valid && !img) seg[nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (EN); \
-            if (img) segi[nimg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u))] = (EN); \
-            nseg += __popcll(mm); nimg += __popcll(mi); }
+            const bool pl = valid && !img; \
+            if (nP + 64 > SEG || nM + 64 > SEG || nF + 64 > SEG || nI + 64 > SEG) flush(); \
+            TS_PUT(segP, nP, (pl && cw != 0 && cw == cs)) TS_PUT(segM, nM, (pl && cw != 0 && cw != cs)) TS_PUT(segF, nF, (pl && cw == 0)) \
+            TS_PUT(segI, nI, img) }
         if (TAB_LDS) {
             for (uint32_t k0 = 0;; k0 += NSLOT) {
                 TS_ROUND(ent, k0)
@@ -296,6 +377,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             }
         }
 #undef TS_ROUND
+#undef TS_PUT
         if (!TAB_LDS && windowed) { TSTAMP(f_copy) flush(); TSTAMP(f_proc) }
     }
     TSTAMP(f_copy)
@@ -303,7 +385,8 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     TSTAMP(f_proc)
     __syncthreads();                                           // every wave is done with the table: its space takes the partial sums
 #pragma unroll
-    for (int r = 0; r < RS; ++r) red[(size_t)wave * TS + r * 64 + lane] = make_double2(accW[r], accS[r]);
+    for (int r = 0; r < RS; ++r)                               // W = P + M, S = P - M + F (+ the image deposits), exact on the weight grid
+        red[(size_t)wave * TS + r * 64 + lane] = make_double2((accP[r] + accM[r]) + accWi[r], ((accP[r] - accM[r]) + accF[r]) + accSi[r]);
     // occupancy of the frame sites (-1 .. TS) from the staged cells
     for (int i = t; i < TS + 2; i += FU_THREADS) {
         int n = 0;
@@ -315,41 +398,50 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         if (lane == 0) { atomicAdd(&misc[4 + 0], (int)s1); atomicAdd(&misc[4 + 1], (int)s2); }
     }
     __syncthreads();
-    // ---------------------------------------------------------------- 2  fresh field + proposals of the frame's particles
-    const double beta = a.beta[e];
-    double2 fnew[NOLD];
+    // ---------------------------------------------------------------- 2  fresh field of the frame sites
 #pragma unroll
     for (int r = 0; r < NOLD; ++r) {
         const int xi = r * FU_THREADS + t;
-        fnew[r] = old[r];
         if (xi < TS && xi < nfr) {
+            double2 f = old[r];
 #pragma unroll
-            for (int w = 0; w < FU_WAVES; ++w) { const double2 pth = red[(size_t)w * TS + xi]; fnew[r].x += pth.x; fnew[r].y += pth.y; }
-            const int s = frame_site(xi);
-            if (s >= 0) {
-                if (M.field_mode && xi >= 2 && xi < 2 + own_n) a.ws_out[(size_t)e * L + s] = fnew[r];
-                double fW = fnew[r].x, fS = fnew[r].y;
-                if (!M.field_mode) { fS = (double)misc[4]; fW = (double)misc[5]; }
-                const int c0 = occL[xi + 1], cl = occL[xi], cr = occL[xi + 2];
-                const bool anch = a.anchor ? a.anchor[s] != 0 : false;
-                if (!a.field_only) for (int k = 0; k < K; ++k) {
-                    const uint32_t c = cellL[(xi + 1) * K + k];
-                    uint8_t code = EV_NONE;
-                    if (c != CELL_EMPTY)
-                        code = draw_proposal(M, anch, s, (c & CELL_PLUS) ? 1 : -1, (c & CELL_BOUND) != 0, fS, fW, beta, c0, cl, cr,
-                                             (uint32_t)step, (uint32_t)(step >> 32), c & CELL_ID, M.ens_base + e);
-                    propL[xi * K + k] = code;
-                }
-            } else {
-                for (int k = 0; k < K; ++k) propL[xi * K + k] = EV_NONE;
-            }
-        } else if (xi < TS) {
-            for (int k = 0; k < K; ++k) propL[xi * K + k] = EV_NONE;
+            for (int w = 0; w < FU_WAVES; ++w) { const double2 pth = red[(size_t)w * TS + xi]; f.x += pth.x; f.y += pth.y; }
+            if (!M.field_mode) f = make_double2((double)misc[5], (double)misc[4]);
+            fieldL[xi] = f;
+            if (M.field_mode && xi >= 2 && xi < 2 + own_n) a.ws_out[(size_t)e * L + frame_site(xi)] = f;
+        }
+    }
+    if (a.field_only) return;                                  // flush of the pending deposits only (observation)
+    __syncthreads();
+    // ---------------------------------------------------------------- 2b proposals, a lane per particle of this wave
+    auto propose_one = [&](const uint2 pc, const uint32_t (&x)[4]) {
+        const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16);
+        const int s = frame_site(pos);
+        const double2 f = fieldL[pos];
+        const bool anch = a.anchor ? a.anchor[s] != 0 : false;
+        propL[pos * K + k] = decide_proposal(M, anch, s, (pc.y & CELL_PLUS) ? 1 : -1, (pc.y & CELL_BOUND) != 0, clip_field(f.y, f.x), beta,
+                                             occL[pos + 1], occL[pos], occL[pos + 2], x);
+    };
+    if (lay.cells_in_regs) {
+        if (lane < n_w) propose_one(mine, rx);
+        for (int j = 64 + lane; j < n_w; j += 64) {            // more than 64 particles in this wave's chunk (dense or K > 1)
+            const uint2 pc = plist[j];
+            uint32_t x[4];
+            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, x);
+            propose_one(pc, x);
+        }
+    } else {
+        for (int c = c_lo + lane; c < c_hi; c += 64) {
+            const uint32_t cw = cellL[c];
+            const int pos = c / K - 1;
+            if (cw == CELL_EMPTY || pos < 0 || pos >= nfr) continue;
+            uint32_t x[4];
+            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), cw & CELL_ID, (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, x);
+            propose_one(make_uint2((uint32_t)pos | ((uint32_t)(c - (pos + 1) * K) << 16), cw), x);
         }
     }
     __syncthreads();
     TSTAMP(f_part)
-    if (a.field_only) return;                                  // flush of the pending deposits only (observation)
     // ---------------------------------------------------------------- 3 + 4  exclusion, new cells of the owned sites, deposits
     // number of proposers of frame site j (0 < j < nfr - 1) with an id below `id`: they sit on j - 1 (moving right) and j + 1 (moving left)
     auto rank_at = [&](int j, uint32_t id) -> int {

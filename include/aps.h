@@ -174,6 +174,14 @@ int aps_resort(aps_handle *h);
  * their summed duration, the number of launches and the work done: pair evaluations (PAIRS) or deposits (LATTICE). */
 int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *launches, double *work);
 
+/* How the last aps_step call ran: steps replayed from captured hipGraphs (runs of 32, 8 and 2 steps) and steps launched
+ * kernel by kernel. */
+int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps);
+
+/* Measurement: bytes read + bytes written per second of a plain 16-byte-per-lane copy kernel over nbytes (>= 1 MiB; use
+ * >= 1 GiB to get past the caches) on the handle's device -- the streaming ceiling of THIS box, quoted beside the spec. */
+int aps_copy_bandwidth(aps_handle *h, int64_t nbytes, int32_t reps, double *gbytes_per_s);
+
 /* What the instrument itself reads: mean elapsed time between two events recorded back to back (nothing in between)
  * on the handle's stream.  Event-bracketed durations of microsecond kernels carry this offset. */
 int aps_event_overhead(aps_handle *h, int32_t reps, double *ms_per_pair);
