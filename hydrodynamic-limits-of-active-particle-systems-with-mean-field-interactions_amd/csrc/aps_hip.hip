@@ -1303,6 +1303,7 @@ struct aps_handle {
     uint32_t *d_cell[2] = {nullptr, nullptr}, *d_tdcnt[2] = {nullptr, nullptr}, *d_tdep[2] = {nullptr, nullptr};
     long long *d_gpart[2] = {nullptr, nullptr};
     uint32_t *d_slot_of = nullptr;
+    Model *d_model = nullptr; TileRare *d_rare = nullptr;      // device copies read by the tile kernel
     int ts_RS = 2, ts_own = 124, ts_ntile = 0, ts_dcap = 0;
     bool ts_table_in_lds = true;
     bool slots_dirty = false;                  // the particle-indexed arrays lag behind the cells
@@ -1673,11 +1674,12 @@ int launch_field_update(aps_handle *h) {
 // ------------------------------------------------------------------------------- tiles formulation, host side
 bool is_tiles(const aps_handle *h) { return h->method == APS_METHOD_TILES; }
 
-const void *ts_kernel(bool periodic, bool tab, int RS) {
-#define TS_CASE(R) case R: return periodic ? (tab ? (const void *)&tile_step<1, true, R> : (const void *)&tile_step<1, false, R>) \
-                                            : (tab ? (const void *)&tile_step<0, true, R> : (const void *)&tile_step<0, false, R>);
+const void *ts_kernel(bool periodic, bool tab, int RS, bool k1) {
+#define TS_PICK(BC, TL, R) (k1 ? (const void *)&tile_step<BC, TL, R, true> : (const void *)&tile_step<BC, TL, R, false>)
+#define TS_CASE(R) case R: return periodic ? (tab ? TS_PICK(1, true, R) : TS_PICK(1, false, R)) : (tab ? TS_PICK(0, true, R) : TS_PICK(0, false, R));
     switch (RS) { TS_CASE(1) TS_CASE(2) TS_CASE(3) TS_CASE(4) TS_CASE(5) TS_CASE(6) TS_CASE(8) default: return nullptr; }
 #undef TS_CASE
+#undef TS_PICK
 }
 constexpr int TS_RS_CHOICES[] = {1, 2, 3, 4, 5, 6, 8};
 
@@ -1692,7 +1694,7 @@ void ts_choose_geometry(aps_handle *h) {
         const double miss = std::fabs(wgs - 2.4 * 256.0);
         if (miss < best) { best = miss; h->ts_RS = rs; }
     }
-    if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r)) h->ts_RS = r; }
+    if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
     h->ts_own = 64 * h->ts_RS - 4;
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
@@ -1702,15 +1704,15 @@ void ts_choose_geometry(aps_handle *h) {
 TileArgs tile_args(aps_handle *h, bool field_only) {
     TileArgs a{};
     const int par = (int)(h->step & 1), out = field_only ? par : par ^ 1;
-    a.m = h->model; a.tlen = h->tlen; a.own = h->ts_own; a.ntile = h->ts_ntile; a.dcap = h->ts_dcap; a.E = h->E; a.par = par;
-    a.tile_lo = 0; a.field_only = field_only ? 1 : 0;
+    a.L = h->p.L; a.K = h->p.K; a.tlen = h->tlen; a.own = h->ts_own; a.ntile = h->ts_ntile; a.dcap = h->ts_dcap; a.par = par;
+    a.tile_lo = 0; a.field_only = field_only ? 1 : 0; a.field_mode = h->model.field_mode; a.ens_base = h->model.ens_base; a.E = h->E;
+    a.seed_lo = h->model.seed_lo; a.seed_hi = h->model.seed_hi;
+    a.model = h->d_model; a.rare = h->d_rare;
     a.ws_in = h->d_wsb[par]; a.ws_out = h->d_wsb[out];
     a.cell_in = h->d_cell[par]; a.cell_out = h->d_cell[par ^ 1];
     a.dcnt_in = h->d_tdcnt[par]; a.dep_in = h->d_tdep[par]; a.dcnt_out = h->d_tdcnt[par ^ 1]; a.dep_out = h->d_tdep[par ^ 1];
     a.gpart_in = h->d_gpart[par]; a.gpart_out = h->d_gpart[par ^ 1];
     a.stepw = h->d_stepw; a.beta = h->d_beta; a.anchor = h->d_anchor;
-    a.exit_log = h->d_exit; a.n_exit = h->d_nexit; a.exit_cap = h->exit_cap;
-    a.src = h->d_src; a.slot_of = h->d_slot_of; a.Npad = (int)h->Npad; a.N = h->N; a.stamps = h->d_stamps;
     return a;
 }
 
@@ -1718,7 +1720,7 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
     int rc = field_only ? APS_OK : prof_mark(h, KIND_TILE_STEP);
     if (rc) return rc;
     TileArgs a = tile_args(h, field_only);
-    const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS);
+    const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1);
     const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K).total;
     const dim3 grid((unsigned)h->ts_ntile, (unsigned)h->E), block(FU_THREADS);
     void *args[] = {(void *)&a, (void *)&h->d_table};
@@ -1975,10 +1977,17 @@ int aps_create(const aps_params *p, aps_handle **out) {
                 return die(rc);
             if (hipMemsetAsync(h->d_cell[b], 0xFF, EL * p->K * 4, h->stream) != hipSuccess) { h->err = "cell init failed"; return die(APS_ERR_HIP); }
         }
+        if ((rc = dev_alloc(h, &h->d_model, 1)) || (rc = dev_alloc(h, &h->d_rare, 1))) return die(rc);
+        {
+            const TileRare rare{h->d_exit, h->d_nexit, h->d_src, h->d_slot_of, h->d_stamps, (long long)h->N, h->exit_cap, (int)h->Npad};
+            if (hipMemcpyAsync(h->d_model, &h->model, sizeof(Model), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(h->d_rare, &rare, sizeof(TileRare), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "tile argument upload failed"; return die(APS_ERR_HIP); }
+        }
         const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K).total;
         if (need > 160 * 1024) { h->err = "tiles: site capacity too large for the tile kernel's LDS staging"; return die(APS_ERR_ARG); }
         if (need > 48 * 1024 &&
-            hipFuncSetAttribute(ts_kernel(p->periodic != 0, h->ts_table_in_lds, h->ts_RS), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
+            hipFuncSetAttribute(ts_kernel(p->periodic != 0, h->ts_table_in_lds, h->ts_RS, p->K == 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
             h->err = "hipFuncSetAttribute(tile_step) failed"; return die(APS_ERR_HIP);
         }
     }
@@ -2004,7 +2013,7 @@ void aps_destroy(aps_handle *h) {
     if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
     for (int b = 0; b < 2; ++b)
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
-    if (h->d_slot_of) (void)hipFree(h->d_slot_of);
+    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare}) if (q) (void)hipFree(q);
     for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_lo_hi, (void *)h->d_ref_ok, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,

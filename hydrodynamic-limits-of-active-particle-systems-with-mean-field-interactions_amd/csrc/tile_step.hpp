@@ -23,11 +23,16 @@
 #pragma once
 
 constexpr uint32_t CELL_EMPTY = 0xFFFFFFFFu, CELL_ID = 0x3FFFFFFFu, CELL_BOUND = 1u << 30, CELL_PLUS = 1u << 31;
-constexpr int TS_CREG = 4;                 // cell words a thread can stage through registers in the prologue
+constexpr int TS_CREG = 4;                 // rounds of 64 cell words a wave can stage through registers (general K)
+
+// what only the rare paths (exits, diagnostic stamps) touch: kept out of the kernel's argument registers
+struct TileRare { double *exit_log; unsigned *n_exit; uint32_t *src; const uint32_t *slot_of; unsigned long long *stamps; long long N; int exit_cap, Npad; };
 
 struct TileArgs {
-    Model m;
-    int tlen, own, ntile, dcap, E, par, tile_lo, field_only;
+    int L, K, tlen, own, ntile, dcap, par, tile_lo, field_only, field_mode, ens_base, E;
+    uint32_t seed_lo, seed_hi;                         // Philox key
+    const Model *model;                                // device copy of the rate parameters (read by the proposal phase)
+    const TileRare *rare;
     const double2 *ws_in; double2 *ws_out;             // [E][L]
     const uint32_t *cell_in; uint32_t *cell_out;       // [E][L][K]
     const uint32_t *dcnt_in, *dep_in;                  // [E][ntile], [E][ntile][dcap]: written by the previous step
@@ -35,10 +40,6 @@ struct TileArgs {
     const long long *gpart_in; long long *gpart_out;   // [E][ntile][2] spin sum / live count per tile (global-field mode)
     unsigned long long *stepw;                         // [2] device step words (see propose_lattice)
     const double *beta; const uint8_t *anchor;
-    double *exit_log; unsigned *n_exit; int exit_cap;
-    uint32_t *src; const uint32_t *slot_of;            // particle-indexed record, touched only by exits
-    int Npad; long long N;
-    unsigned long long *stamps;
 };
 
 // slots per bucket and load, buckets per group: TAB_LDS 4 buckets x 16 slots per wave (16 buckets per group);
@@ -46,6 +47,7 @@ struct TileArgs {
 template <bool TAB_LDS> struct TsGeom { static constexpr int SB = TAB_LDS ? 4 : 5, NSLOT = 1 << SB, GB = FU_WAVES * (64 >> SB); };
 
 __host__ __device__ inline int ts_table_pad(int RS, int own) { return 64 * RS + own + 2; }
+__host__ __device__ inline int ts_table_chunks(int tlen, int RS, int own) { return (tlen + ts_table_pad(RS, own) + 1 + 127) / 128; }   // 1 KB each
 __host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TsGeom<false>::GB * own) + 64 * RS + 8 + 127) / 128 * 128; }
 constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
 struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
@@ -61,14 +63,20 @@ __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, i
     l.occ = l.props + (TS * K + 7) / 8 * 8;
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
     l.plist = l.misc + 64;
-    l.tab = l.plist + (l.cells_in_regs ? (size_t)FU_WAVES * l.Q * 8 : 0);
-    const size_t table = tab_lds ? ((size_t)tlen + 2 + ts_table_pad(RS, own)) / 2 * 2 * sizeof(double)
-                                 : (size_t)2 * ts_win_entries(RS, own) * sizeof(double);
+    l.tab = (l.plist + (l.cells_in_regs ? (size_t)FU_WAVES * l.Q * 8 : 0) + 15) / 16 * 16;
+    const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own) * 1024 : (size_t)2 * ts_win_entries(RS, own) * sizeof(double);
     const size_t red = (size_t)FU_WAVES * TS * sizeof(double2);
     l.field = l.tab + red;                                      // fresh {W, S} of the frame sites, behind the partial sums
     const size_t after = red + TS * sizeof(double2);
     l.total = l.tab + (table > after ? table : after);
     return l;
+}
+
+// |a - b| + c with b wave-uniform (a deposit's site * 8 in a scalar register)
+__device__ __forceinline__ uint32_t sad3s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
 }
 
 // weights of four wave-uniform deposits at this lane's RS sites.  VAR 0: interior (padded LDS table or window: no clamp),
@@ -82,10 +90,10 @@ __device__ __forceinline__ void ts_weights(const uint32_t (&ent)[4], const uint3
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             if (VAR == 0) {
-                const uint32_t d = sad3(x8[r], p8, tbase);
+                const uint32_t d = sad3s(x8[r], p8, tbase);
                 w[k][r] = table_at<TAB_LDS>(table_g, TAB_LDS ? d : min(d, tlen8));
             } else {
-                const uint32_t d8 = sad3(x8[r], p8, 0u);
+                const uint32_t d8 = sad3s(x8[r], p8, 0u);
                 w[k][r] = table_at<TAB_LDS>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
             }
         }
@@ -110,14 +118,15 @@ __device__ __forceinline__ void ts_group(const uint4 q, const uint32_t (&x8)[RS]
     }
 }
 
-template <int BC, bool TAB_LDS, int RS>
+// K1: site capacity 1 (one cell per site): every loop over a site's cells disappears
+template <int BC, bool TAB_LDS, int RS, bool K1>
 __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const double *__restrict__ table_g) {
     constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS;
     constexpr int SEG = TS_SEG;
     constexpr int SB = TsGeom<TAB_LDS>::SB, NSLOT = TsGeom<TAB_LDS>::NSLOT, GB = TsGeom<TAB_LDS>::GB;
+    constexpr int NR = K1 ? ((TS + 2 + FU_WAVES - 1) / FU_WAVES + 63) / 64 : TS_CREG;   // register rounds of the wave's cell chunk
     extern __shared__ double lds[];
-    const Model &M = a.m;
-    const int L = M.L, K = M.K, OWN = a.own;
+    const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
     const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K);
     char *lds_c = reinterpret_cast<char *>(lds);
     uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
@@ -136,16 +145,16 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     const int x0 = own0 - 2;                                   // site of frame position 0 (may lie outside the lattice)
     const int x0c = max(x0, 0), x1c = min(x0 + TS - 1, L - 1); // the frame clipped to the lattice (range tests)
     const int Rt = a.tlen - 1;
-    const unsigned long long step = a.stepw[a.par];
-    const double beta = a.beta[e];
-    if (blockIdx.x == 0 && e == 0 && t == 0 && !a.field_only) a.stepw[a.par ^ 1] = step + 1ull;   // nobody reads that word during this step
-    // site of frame position i (position -1 .. TS); -1 = no such site (beyond a wall, or beyond the valid frame)
-    auto frame_site = [&](int i) -> int {
-        if (i < -1 || i > nfr) return -1;
-        int s = x0 + i;
-        if (BC == 1) { s %= L; if (s < 0) s += L; return s; }
-        return (s < 0 || s >= L) ? -1 : s;
-    };
+    // per-ensemble bases (scalar); everything below indexes them with 32-bit offsets
+    const uint32_t *__restrict__ cell_e = a.cell_in + (size_t)e * L * K;
+    const double2 *__restrict__ ws_e = a.ws_in + (size_t)e * L;
+    const uint32_t *__restrict__ dcnt_e = a.dcnt_in + (size_t)e * a.ntile;
+    const uint32_t *__restrict__ dep_e = a.dep_in + (size_t)e * a.ntile * a.dcap;
+    uint32_t tbase = 0;
+    {
+        typedef __attribute__((address_space(3))) double lds_double;
+        tbase = (uint32_t)(size_t)(lds_double *)tab;          // LDS byte offset of the table (or of the windows)
+    }
 #ifdef APS_STAMPS
     unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_part = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long f_start = t0, r_start = __builtin_amdgcn_s_memrealtime();
@@ -154,31 +163,54 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
 #define TSTAMP(var)
 #endif
     // ---------------------------------------------------------------- requests that depend on nothing
-    // The cells of the frame (+1 site either side), a contiguous chunk of Q cells per wave.  When a chunk fits the
-    // wave's registers the wave compacts ITS particles right away (ballot + mbcnt, no barrier) and draws their Philox
-    // numbers while the table and the deposit lists are still on their way.
+    // The table goes straight into LDS (LDS-direct loads, 1 KB per wave instruction, no registers); the global copy is
+    // followed by zeros, so the padded tail comes along.  Written as inline assembly like the windows below (the compiler
+    // would put an s_waitcnt vmcnt(0) in front of every later LDS read); the wait in front of the barrier orders it.
+    if (TAB_LDS) {
+        const int nchunk = ts_table_chunks(a.tlen, RS, OWN);
+        const double *srct = table_g + lane * 2;
+        for (int c = wave; c < nchunk; c += FU_WAVES) {
+            const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tbase + (uint32_t)c * 1024u));
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srct + c * 128) : "memory");
+        }
+    }
+    const unsigned long long step = a.stepw[a.par];
+    const double beta = a.beta[e];
+    if (blockIdx.x == 0 && e == 0 && t == 0 && !a.field_only) a.stepw[a.par ^ 1] = step + 1ull;   // nobody reads that word during this step
+    // site of frame position i (-1 .. nfr), or -1: no such site (beyond a wall, or beyond the valid frame)
+    auto frame_site = [&](int i) -> int {
+        if (i < -1 || i > nfr) return -1;
+        int s = x0 + i;
+        if (BC == 1) { s %= L; if (s < 0) s += L; return s; }
+        return (s < 0 || s >= L) ? -1 : s;
+    };
+    // The cells of the frame (+1 site either side), a contiguous chunk of Q cells per wave, through registers when a
+    // chunk fits: the wave then compacts ITS particles right away (ballot + mbcnt, no barrier) and draws their Philox
+    // numbers before the sweep.  All loads are unconditional (clamped addresses, values selected afterwards).
     const int ncell = (TS + 2) * K, Q = lay.Q;
     const int c_lo = wave * Q, c_hi = min(c_lo + Q, ncell);
-    uint32_t creg[TS_CREG];
-    int cpk[TS_CREG];
-    if (lay.cells_in_regs) {
+    uint32_t creg[NR];
+    int cpk[NR];
+    const bool regs = K1 || lay.cells_in_regs;
+    if (regs) {
 #pragma unroll
-        for (int u = 0; u < TS_CREG; ++u) {
+        for (int u = 0; u < NR; ++u) {
             const int c = c_lo + lane + 64 * u;
-            const int pos = K == 1 ? c - 1 : c / K - 1, k = K == 1 ? 0 : c - (pos + 1) * K;
+            const int pos = K1 ? c - 1 : c / K - 1, k = K1 ? 0 : c - (pos + 1) * K;
             const int s = c < c_hi ? frame_site(pos) : -1;
-            creg[u] = s >= 0 ? a.cell_in[((size_t)e * L + s) * K + k] : CELL_EMPTY;
-            cpk[u] = (pos >= 0 && pos < nfr) ? (pos | (k << 16)) : -1;
+            creg[u] = cell_e[(unsigned)max(s, 0) * (unsigned)K + (unsigned)k];
+            cpk[u] = s < 0 ? -2 : ((pos >= 0 && pos < nfr) ? (pos | (k << 16)) : -1);   // -2: no site, -1: only an occupancy neighbour
         }
     } else {
         for (int c = t; c < ncell; c += FU_THREADS) {
             const int s = frame_site(c / K - 1);
-            cellL[c] = s >= 0 ? a.cell_in[((size_t)e * L + s) * K + c % K] : CELL_EMPTY;
+            const uint32_t v = cell_e[(unsigned)max(s, 0) * (unsigned)K + (unsigned)(c % K)];
+            cellL[c] = s >= 0 ? v : CELL_EMPTY;
         }
     }
     // buckets (= tiles) whose deposits can reach the frame: one run of nbk buckets from b0 that may wrap around the torus
     int b0 = 0, nbk = 0;
-    if (M.field_mode) {
+    if (a.field_mode) {
         if (BC == 0) {
             b0 = max(0, x0c - Rt - 1) / OWN;
             nbk = min(L - 1, x1c + Rt + 1) / OWN - b0 + 1;
@@ -196,42 +228,41 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     }
     const bool wall = BC == 0 && ((x0c + 1 <= Rt) || (L - x1c <= Rt));   // an image term can be non-zero
     const int sub = lane >> SB, slot = lane & (NSLOT - 1);
+    const unsigned slot_c = (unsigned)min(slot, a.dcap - 1);
     uint32_t pre_cnt[FU_PRE], pre_ent[FU_PRE];
 #pragma unroll
     for (int j = 0; j < FU_PRE; ++j) {
         const int bi = j * GB + sub * FU_WAVES + wave;
-        int b = b0 + bi;
-        if (b >= a.ntile) b -= a.ntile;
         const bool ok = bi < nbk;
-        pre_cnt[j] = ok ? a.dcnt_in[(size_t)e * a.ntile + b] : 0u;
-        pre_ent[j] = (ok && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + slot] : DEP_NULL;
-    }
-    double tv[FU_TREG];
-    if (TAB_LDS) {
-#pragma unroll
-        for (int u = 0; u < FU_TREG; ++u) { const int i = t + u * FU_THREADS; tv[u] = i < a.tlen ? table_g[i] : 0.0; }
+        int b = b0 + (ok ? bi : 0);
+        if (b >= a.ntile) b -= a.ntile;
+        pre_cnt[j] = dcnt_e[(unsigned)b];                      // entries beyond the count are never looked at
+        pre_ent[j] = dep_e[(unsigned)b * (unsigned)a.dcap + slot_c];
+        if (!ok) pre_cnt[j] = 0u;
     }
     double2 old[NOLD];
 #pragma unroll
     for (int r = 0; r < NOLD; ++r) {
         const int xi = r * FU_THREADS + t;
         const int s = (xi < TS && xi < nfr) ? frame_site(xi) : -1;
-        old[r] = (s >= 0 && M.field_mode) ? a.ws_in[(size_t)e * L + s] : make_double2(0.0, 0.0);
+        old[r] = ws_e[(unsigned)max(s, 0)];
+        if (s < 0 || !a.field_mode) old[r] = make_double2(0.0, 0.0);
     }
     // global-field mode (ref :219-221): the sums over all particles = sum of the tiles' parts
     long long gS = 0, gN = 0;
-    if (!M.field_mode) {
+    if (!a.field_mode) {
         for (int i = t; i < a.ntile; i += FU_THREADS) { gS += a.gpart_in[((size_t)e * a.ntile + i) * 2]; gN += a.gpart_in[((size_t)e * a.ntile + i) * 2 + 1]; }
     }
     if (t < 8) misc[t] = 0;
     for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;   // EV_NONE everywhere
-    // this wave's particles (needs only the cell loads, the oldest requests) and their random numbers
+    // this wave's particles and their random numbers
     int n_w = 0;
     uint2 mine = make_uint2(0u, CELL_EMPTY);
     uint32_t rx[4] = {0u, 0u, 0u, 0u};
-    if (lay.cells_in_regs) {
+    if (regs) {
 #pragma unroll
-        for (int u = 0; u < TS_CREG; ++u) {
+        for (int u = 0; u < NR; ++u) {
+            if (cpk[u] == -2) creg[u] = CELL_EMPTY;
             const bool occ = creg[u] != CELL_EMPTY && cpk[u] >= 0;
             const unsigned long long mm = __ballot(occ);
             if (occ) plist[n_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)cpk[u], creg[u]);
@@ -239,19 +270,10 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         }
         if (!a.field_only && lane < n_w) {
             mine = plist[lane];
-            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, rx);
+            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, rx);
         }
 #pragma unroll
-        for (int u = 0; u < TS_CREG; ++u) { const int c = c_lo + lane + 64 * u; if (c < c_hi) cellL[c] = creg[u]; }
-    }
-    const int tpad = TAB_LDS ? a.tlen + ts_table_pad(RS, OWN) : 0;
-    uint32_t tbase = 0;
-    if (TAB_LDS) {
-        typedef __attribute__((address_space(3))) double lds_double;
-        tbase = (uint32_t)(size_t)(lds_double *)tab;
-#pragma unroll
-        for (int u = 0; u < FU_TREG; ++u) { const int i = t + u * FU_THREADS; if (i <= tpad) tab[i] = tv[u]; }
-        for (int i = t + FU_TREG * FU_THREADS; i <= tpad; i += FU_THREADS) tab[i] = i < a.tlen ? table_g[i] : 0.0;
+        for (int u = 0; u < NR; ++u) { const int c = c_lo + lane + 64 * u; if (c < c_hi) cellL[c] = creg[u]; }
     }
     const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)L << 3;
     uint32_t x8[RS];
@@ -262,16 +284,14 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         if (BC == 1) { s %= L; if (s < 0) s += L; } else s = min(max(s, 0), L - 1);
         x8[r] = (uint32_t)s << 3; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0.0;
     }
+    if (TAB_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's table chunks have landed
     __syncthreads();                                           // table and cells staged
     TSTAMP(f_stage)
     // ---------------------------------------------------------------- 1  deposits of the previous step -> W, S of the frame
     const bool windowed = !TAB_LDS && BC == 0 && !wall;
-    uint32_t win_base = 0;
-    if (!TAB_LDS) {
-        typedef __attribute__((address_space(3))) double lds_double;
-        win_base = (uint32_t)(size_t)(lds_double *)tab;
-    }
-    const uint32_t win_lds = win_base;
+    const uint32_t tb = TAB_LDS ? tbase : 0u;                  // table in global memory: byte offsets from its start
+    uint32_t win_base = tbase;
+    const uint32_t win_lds = tbase;
     const int WIN = ts_win_entries(RS, OWN);
     int null_site = x0c;
     int dmin_next = 0, null_next = x0c;
@@ -292,22 +312,24 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     const uint4 *segP4 = reinterpret_cast<const uint4 *>(segP), *segM4 = reinterpret_cast<const uint4 *>(segM),
                 *segF4 = reinterpret_cast<const uint4 *>(segF), *segI4 = reinterpret_cast<const uint4 *>(segI);
     auto flush = [&]() {                                       // sweep the frame with the segments' deposits, class by class
-        if (lane < 4) {
+        if (lane < 8) {                                        // pad to whole groups of four, one group beyond (the sweep reads one group ahead)
             const uint32_t pad = DEP_NULL | (uint32_t)null_site;   // a site whose distances stay in table range, coefficients 0
             segP[nP + lane] = pad; segM[nM + lane] = pad; segF[nF + lane] = pad; segI[nI + lane] = DEP_NULL | (uint32_t)x0c;
         }
-#define TS_SWEEP(SEG4, N, MODE, ACC) \
+#define TS_SWEEP(SEG4, N, MODE, ACC) { \
+        uint4 q = SEG4[0]; \
         _Pragma("unroll 1") for (int i = 0; i < ((N) + 3) >> 2; ++i) { \
-            const uint4 q = SEG4[i]; \
-            if (BC == 1) ts_group<1, TAB_LDS, RS, MODE>(q, x8, tbase, table_g, tlen8, L8, ACC); \
+            const uint4 qn = SEG4[i + 1];                      /* next group's entries: in flight during this group's gathers */ \
+            if (BC == 1) ts_group<1, TAB_LDS, RS, MODE>(q, x8, tb, table_g, tlen8, L8, ACC); \
             else if (!TAB_LDS && windowed) ts_group<0, true, RS, MODE>(q, x8, win_base, table_g, tlen8, L8, ACC); \
-            else ts_group<0, TAB_LDS, RS, MODE>(q, x8, tbase, table_g, tlen8, L8, ACC); }
+            else ts_group<0, TAB_LDS, RS, MODE>(q, x8, tb, table_g, tlen8, L8, ACC); \
+            q = qn; } }
         TS_SWEEP(segP4, nP, 0, accP)
         TS_SWEEP(segM4, nM, 0, accM)
         TS_SWEEP(segF4, nF, 1, accF)
 #undef TS_SWEEP
 #pragma unroll 1
-        for (int i = 0; i < (nI + 3) >> 2; ++i) fu_group<2, TAB_LDS, RS>(segI4[i], x8, tbase, table_g, tlen8, L8, accWi, accSi);
+        for (int i = 0; i < (nI + 3) >> 2; ++i) fu_group<2, TAB_LDS, RS>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
 #ifdef APS_STAMPS
         f_n += nP + nM + nF + nI;
 #endif
@@ -318,15 +340,16 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     uint32_t nx_cnt = 0u, nx_ent = DEP_NULL;
     for (int j = 0; j < ngroups; ++j) {
         const int bi = j * GB + sub * FU_WAVES + wave;
-        int b = b0 + bi;
-        if (b >= a.ntile) b -= a.ntile;
         const bool ok = bi < nbk;
+        int b = b0 + (ok ? bi : 0);
+        if (b >= a.ntile) b -= a.ntile;
         uint32_t cnt, ent;
         if (j < FU_PRE) { cnt = j == 0 ? pre_cnt[0] : pre_cnt[FU_PRE - 1]; ent = j == 0 ? pre_ent[0] : pre_ent[FU_PRE - 1]; }
         else if (!TAB_LDS) { cnt = nx_cnt; ent = nx_ent; }
         else {
-            cnt = ok ? a.dcnt_in[(size_t)e * a.ntile + b] : 0u;
-            ent = (ok && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + slot] : DEP_NULL;
+            cnt = dcnt_e[(unsigned)b];
+            ent = dep_e[(unsigned)b * (unsigned)a.dcap + slot_c];
+            if (!ok) cnt = 0u;
         }
         if (!TAB_LDS) {
             TSTAMP(f_copy)
@@ -342,11 +365,12 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         }
         if (!TAB_LDS && j + 1 >= FU_PRE && j + 1 < ngroups) {
             const int bi1 = (j + 1) * GB + sub * FU_WAVES + wave;
-            int b1 = b0 + bi1;
-            if (b1 >= a.ntile) b1 -= a.ntile;
             const bool ok1 = bi1 < nbk;
-            nx_cnt = ok1 ? a.dcnt_in[(size_t)e * a.ntile + b1] : 0u;
-            nx_ent = (ok1 && slot < a.dcap) ? a.dep_in[((size_t)e * a.ntile + b1) * a.dcap + slot] : DEP_NULL;
+            int b1 = b0 + (ok1 ? bi1 : 0);
+            if (b1 >= a.ntile) b1 -= a.ntile;
+            nx_cnt = dcnt_e[(unsigned)b1];
+            nx_ent = dep_e[(unsigned)b1 * (unsigned)a.dcap + slot_c];
+            if (!ok1) nx_cnt = 0u;
         }
         cnt = min(cnt, (uint32_t)a.dcap);
         // NSLOT slots of each of the wave's buckets: compact the valid ones into the wave's segments by class.  Near a
@@ -360,19 +384,19 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             const int dp = (int)(en_ & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2; \
             const bool img = valid && wall && ((x0c + dp + 1 <= Rt) || (2 * L - 1 - x1c - dp <= Rt)); \
             const bool pl = valid && !img; \
-            if (nP + 64 > SEG || nM + 64 > SEG || nF + 64 > SEG || nI + 64 > SEG) flush(); \
+            if (nP + 64 > SEG - 4 || nM + 64 > SEG - 4 || nF + 64 > SEG - 4 || nI + 64 > SEG - 4) flush(); \
             TS_PUT(segP, nP, (pl && cw != 0 && cw == cs)) TS_PUT(segM, nM, (pl && cw != 0 && cw != cs)) TS_PUT(segF, nF, (pl && cw == 0)) \
-            TS_PUT(segI, nI, img) }
+            if (wall) TS_PUT(segI, nI, img) }
         if (TAB_LDS) {
             for (uint32_t k0 = 0;; k0 += NSLOT) {
                 TS_ROUND(ent, k0)
                 if (!__ballot(k0 + NSLOT < cnt)) break;
-                ent = (k0 + NSLOT + slot < cnt) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + k0 + NSLOT + slot] : DEP_NULL;
+                ent = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + NSLOT + slot, (uint32_t)a.dcap - 1u)];
             }
         } else {
             TS_ROUND(ent, 0u)
             for (uint32_t k0 = NSLOT; __ballot(k0 < cnt); k0 += NSLOT) {
-                const uint32_t en = (k0 + slot < cnt) ? a.dep_in[((size_t)e * a.ntile + b) * a.dcap + k0 + slot] : DEP_NULL;
+                const uint32_t en = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + slot, (uint32_t)a.dcap - 1u)];
                 TS_ROUND(en, k0)
             }
         }
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         for (int k = 0; k < K; ++k) n += cellL[i * K + k] != CELL_EMPTY;
         occL[i] = (uint8_t)n;
     }
-    if (!M.field_mode) {                                       // workgroup sums of the global-field parts
+    if (!a.field_mode) {                                       // workgroup sums of the global-field parts
         const long long s1 = wave_sum(gS), s2 = wave_sum(gN);
         if (lane == 0) { atomicAdd(&misc[4 + 0], (int)s1); atomicAdd(&misc[4 + 1], (int)s2); }
     }
@@ -406,38 +430,41 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             double2 f = old[r];
 #pragma unroll
             for (int w = 0; w < FU_WAVES; ++w) { const double2 pth = red[(size_t)w * TS + xi]; f.x += pth.x; f.y += pth.y; }
-            if (!M.field_mode) f = make_double2((double)misc[5], (double)misc[4]);
+            if (!a.field_mode) f = make_double2((double)misc[5], (double)misc[4]);
             fieldL[xi] = f;
-            if (M.field_mode && xi >= 2 && xi < 2 + own_n) a.ws_out[(size_t)e * L + frame_site(xi)] = f;
+            if (a.field_mode && xi >= 2 && xi < 2 + own_n) a.ws_out[(size_t)e * L + (unsigned)frame_site(xi)] = f;
         }
     }
     if (a.field_only) return;                                  // flush of the pending deposits only (observation)
     __syncthreads();
     // ---------------------------------------------------------------- 2b proposals, a lane per particle of this wave
-    auto propose_one = [&](const uint2 pc, const uint32_t (&x)[4]) {
-        const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16);
-        const int s = frame_site(pos);
-        const double2 f = fieldL[pos];
-        const bool anch = a.anchor ? a.anchor[s] != 0 : false;
-        propL[pos * K + k] = decide_proposal(M, anch, s, (pc.y & CELL_PLUS) ? 1 : -1, (pc.y & CELL_BOUND) != 0, clip_field(f.y, f.x), beta,
-                                             occL[pos + 1], occL[pos], occL[pos + 2], x);
-    };
-    if (lay.cells_in_regs) {
-        if (lane < n_w) propose_one(mine, rx);
-        for (int j = 64 + lane; j < n_w; j += 64) {            // more than 64 particles in this wave's chunk (dense or K > 1)
-            const uint2 pc = plist[j];
-            uint32_t x[4];
-            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, x);
-            propose_one(pc, x);
-        }
-    } else {
-        for (int c = c_lo + lane; c < c_hi; c += 64) {
-            const uint32_t cw = cellL[c];
-            const int pos = c / K - 1;
-            if (cw == CELL_EMPTY || pos < 0 || pos >= nfr) continue;
-            uint32_t x[4];
-            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), cw & CELL_ID, (uint32_t)(M.ens_base + e), M.seed_lo, M.seed_hi, x);
-            propose_one(make_uint2((uint32_t)pos | ((uint32_t)(c - (pos + 1) * K) << 16), cw), x);
+    {
+        const Model M = *a.model;                              // uniform address: scalar loads, only now
+        auto propose_one = [&](const uint2 pc, const uint32_t (&x)[4]) {
+            const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16);
+            const int s = frame_site(pos);
+            const double2 f = fieldL[pos];
+            const bool anch = a.anchor ? a.anchor[s] != 0 : false;
+            propL[pos * K + k] = decide_proposal(M, anch, s, (pc.y & CELL_PLUS) ? 1 : -1, (pc.y & CELL_BOUND) != 0, clip_field(f.y, f.x), beta,
+                                                 occL[pos + 1], occL[pos], occL[pos + 2], x);
+        };
+        if (regs) {
+            if (lane < n_w) propose_one(mine, rx);
+            for (int j = 64 + lane; j < n_w; j += 64) {        // more than 64 particles in this wave's chunk (dense or K > 1)
+                const uint2 pc = plist[j];
+                uint32_t x[4];
+                philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
+                propose_one(pc, x);
+            }
+        } else {
+            for (int c = c_lo + lane; c < c_hi; c += 64) {
+                const uint32_t cw = cellL[c];
+                const int pos = c / K - 1;
+                if (cw == CELL_EMPTY || pos < 0 || pos >= nfr) continue;
+                uint32_t x[4];
+                philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), cw & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
+                propose_one(make_uint2((uint32_t)pos | ((uint32_t)(c - (pos + 1) * K) << 16), cw), x);
+            }
         }
     }
     __syncthreads();
@@ -455,14 +482,15 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         return n;
     };
     auto cap_at = [&](int j) -> int { const int c = K - (int)occL[j + 1]; return c < 1 ? 1 : (c > 32 ? 32 : c); };
-    const size_t dep_base = ((size_t)e * a.ntile + tile) * a.dcap;
+    uint32_t *dep_o = a.dep_out + ((size_t)e * a.ntile + tile) * a.dcap;
+    uint32_t *cell_o = a.cell_out + (size_t)e * L * K;
     int my_spin = 0, my_live = 0;
 #pragma unroll
     for (int r = 0; r < NOLD; ++r) {
         const int xi = r * FU_THREADS + t;
         if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
         const int s = frame_site(xi);
-        uint32_t *out = a.cell_out + ((size_t)e * L + s) * K;
+        uint32_t *out = cell_o + (unsigned)s * (unsigned)K;
         int n_out = 0;
         for (int k = 0; k < K; ++k) {                          // the particles on this site: stay (possibly changed) or leave
             uint32_t c = cellL[(xi + 1) * K + k];
@@ -482,19 +510,20 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             else if (ev == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
             else if (ev == EV_EXIT) {
                 stays = false;
-                const unsigned kx = atomicAdd(&a.n_exit[e], 1u);
-                if ((int)kx < a.exit_cap) {
-                    double *row = a.exit_log + ((size_t)e * a.exit_cap + kx) * 3;
+                const TileRare R = *a.rare;
+                const unsigned kx = atomicAdd(&R.n_exit[e], 1u);
+                if ((int)kx < R.exit_cap) {
+                    double *row = R.exit_log + ((size_t)e * R.exit_cap + kx) * 3;
                     row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
                 }
-                a.src[(size_t)e * a.Npad + a.slot_of[(size_t)e * a.N + (c & CELL_ID)]] =
+                R.src[(size_t)e * R.Npad + R.slot_of[(size_t)e * R.N + (c & CELL_ID)]] =
                     (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
                 d0 = deposit(s, -1, -sgn); nd = 1;
             }
             if (stays) { out[n_out++] = c; my_spin += (c & CELL_PLUS) ? 1 : -1; my_live += 1; }
-            if (nd && M.field_mode) {
+            if (nd && a.field_mode) {
                 const int kd = atomicAdd(&misc[0], nd);
-                if (kd + nd <= a.dcap) { a.dep_out[dep_base + kd] = d0; if (nd == 2) a.dep_out[dep_base + kd + 1] = d1; }
+                if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
             }
         }
         const int cap = cap_at(xi);
@@ -510,22 +539,22 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         }
         for (int k = n_out; k < K; ++k) out[k] = CELL_EMPTY;
     }
-    if (!M.field_mode) {
+    if (!a.field_mode) {
         const long long s1 = wave_sum((long long)my_spin), s2 = wave_sum((long long)my_live);
         if (lane == 0) { atomicAdd(&misc[1], (int)s1); atomicAdd(&misc[2], (int)s2); }
     }
     __syncthreads();
     if (t == 0) {
         a.dcnt_out[(size_t)e * a.ntile + tile] = (uint32_t)min(misc[0], a.dcap);
-        if (!M.field_mode) {
+        if (!a.field_mode) {
             a.gpart_out[((size_t)e * a.ntile + tile) * 2] = misc[1];
             a.gpart_out[((size_t)e * a.ntile + tile) * 2 + 1] = misc[2];
         }
     }
 #ifdef APS_STAMPS
     TSTAMP(f_cnt)
-    if (t == 0 && a.stamps && blockIdx.x < 4096) {
-        unsigned long long *o = a.stamps + (size_t)blockIdx.x * 8;
+    if (t == 0 && blockIdx.x < 4096) {
+        unsigned long long *o = a.rare->stamps + (size_t)blockIdx.x * 8;
         o[0] = f_cnt; o[1] = f_stage; o[2] = f_copy; o[3] = f_proc; o[4] = __builtin_amdgcn_s_memtime() - f_start;
         o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = r_start; o[7] = f_part;
     }
