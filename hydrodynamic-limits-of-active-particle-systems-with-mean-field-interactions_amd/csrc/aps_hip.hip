@@ -1677,13 +1677,15 @@ bool is_tiles(const aps_handle *h) { return h->method == APS_METHOD_TILES; }
 const void *ts_kernel(bool periodic, bool tab, int RS, bool k1) {
 #define TS_PICK(BC, TL, R) (k1 ? (const void *)&tile_step<BC, TL, R, true> : (const void *)&tile_step<BC, TL, R, false>)
 #define TS_CASE(R) case R: return periodic ? (tab ? TS_PICK(1, true, R) : TS_PICK(1, false, R)) : (tab ? TS_PICK(0, true, R) : TS_PICK(0, false, R));
-    switch (RS) { TS_CASE(1) TS_CASE(2) TS_CASE(3) TS_CASE(4) TS_CASE(5) TS_CASE(6) TS_CASE(8) default: return nullptr; }
+    switch (RS) { TS_CASE(1) TS_CASE(2) TS_CASE(3) TS_CASE(4) TS_CASE(5) TS_CASE(6) TS_CASE(7) TS_CASE(8) default: return nullptr; }
 #undef TS_CASE
 #undef TS_PICK
 }
-constexpr int TS_RS_CHOICES[] = {1, 2, 3, 4, 5, 6, 8};
+constexpr int TS_RS_CHOICES[] = {1, 2, 3, 4, 5, 6, 7, 8};
 
-// tile geometry: the frame size (64 RS sites) that gives about 2.4 workgroups per CU, table in LDS when it fits
+// tile geometry (measured on MI355X, profiles/r02_*): while the whole grid is resident at once (<= 3 workgroups per CU)
+// the frame that gives about 2.4 workgroups per CU is fastest (64 * 5 sites at L = 2e5); larger grids run in waves of
+// workgroups and want the frame with the best work per instruction: 256 sites with the table in LDS, 384 with windows
 void ts_choose_geometry(aps_handle *h) {
     const int L = h->p.L;
     h->ts_RS = 1;
@@ -1694,8 +1696,11 @@ void ts_choose_geometry(aps_handle *h) {
         const double miss = std::fabs(wgs - 2.4 * 256.0);
         if (miss < best) { best = miss; h->ts_RS = rs; }
     }
+    if ((double)(((int64_t)L + 507) / 508) * h->E > 3.0 * 256.0)      // even the largest frame leaves more than 3 per CU
+        h->ts_RS = ts_lds_layout(h->tlen, true, 4, 252, h->p.K).total <= 160 * 1024 ? 4 : 6;
     if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
     h->ts_own = 64 * h->ts_RS - 4;
+    if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 1 && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
     h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K).total <= 160 * 1024;

@@ -118,6 +118,32 @@ __device__ __forceinline__ void ts_group(const uint4 q, const uint32_t (&x8)[RS]
     }
 }
 
+// Inside the kernel sites carry a bias so that the mirror images of deposits beyond a reflecting wall (sites -1 - p and
+// 2L - 1 - p) are ordinary, non-negative site numbers: |x - p| is what the sweep computes, biased or not.
+constexpr uint32_t TS_BIAS = 1u << 26;     // L <= 2^25 and reach <= L: every biased site stays below 2^27 (the entry's site field)
+
+// small boxes only (reach comparable to L: a deposit's two wall images can both matter within one frame): direct term +
+// folded image term per lane, W and S accumulated separately
+template <bool TAB_LDS, int RS>
+__device__ __forceinline__ void ts_image_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase, const double *__restrict__ table_g,
+                                               const uint32_t tlen8, const uint32_t L8, double (&accW)[RS], double (&accS)[RS]) {
+    const uint32_t ent[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t p8 = (ent[k] & POS_MASK) << 3;            // biased, like x8
+        const double cw = (double)((int)((ent[k] >> 27) & 3u) - 1), cs = (double)((int)(ent[k] >> 29) - 2);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const uint32_t s8 = x8[r] + p8 + 8u - 2u * (TS_BIAS << 3);   // (x + p + 1) * 8
+            const double w = table_at<TAB_LDS>(table_g, min(sad3s(x8[r], p8, 0u), tlen8) + tbase) +
+                             table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
+            accW[r] = fma(w, cw, accW[r]);
+            accS[r] = fma(w, cs, accS[r]);
+        }
+    }
+}
+
 // K1: site capacity 1 (one cell per site): every loop over a site's cells disappears
 template <int BC, bool TAB_LDS, int RS, bool K1>
 __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const double *__restrict__ table_g) {
@@ -227,6 +253,9 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         }
     }
     const bool wall = BC == 0 && ((x0c + 1 <= Rt) || (L - x1c <= Rt));   // an image term can be non-zero
+    // box much wider than the reach: at most one wall image of a deposit can matter to one frame, and where it is out of a
+    // lane's reach the zero-padded table says so -- the image is then just another plain deposit (at the mirrored site)
+    const bool mirror_ok = 2 * Rt + TS + OWN + 4 < L;
     const int sub = lane >> SB, slot = lane & (NSLOT - 1);
     const unsigned slot_c = (unsigned)min(slot, a.dcap - 1);
     uint32_t pre_cnt[FU_PRE], pre_ent[FU_PRE];
@@ -282,7 +311,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     for (int r = 0; r < RS; ++r) {
         int s = x0 + r * 64 + lane;
         if (BC == 1) { s %= L; if (s < 0) s += L; } else s = min(max(s, 0), L - 1);
-        x8[r] = (uint32_t)s << 3; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0.0;
+        x8[r] = ((uint32_t)s + TS_BIAS) << 3; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0.0;
     }
     if (TAB_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's table chunks have landed
     __syncthreads();                                           // table and cells staged
@@ -313,8 +342,8 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                 *segF4 = reinterpret_cast<const uint4 *>(segF), *segI4 = reinterpret_cast<const uint4 *>(segI);
     auto flush = [&]() {                                       // sweep the frame with the segments' deposits, class by class
         if (lane < 8) {                                        // pad to whole groups of four, one group beyond (the sweep reads one group ahead)
-            const uint32_t pad = DEP_NULL | (uint32_t)null_site;   // a site whose distances stay in table range, coefficients 0
-            segP[nP + lane] = pad; segM[nM + lane] = pad; segF[nF + lane] = pad; segI[nI + lane] = DEP_NULL | (uint32_t)x0c;
+            const uint32_t pad = DEP_NULL | ((uint32_t)null_site + TS_BIAS);   // a site whose distances stay in table range, coefficients 0
+            segP[nP + lane] = pad; segM[nM + lane] = pad; segF[nF + lane] = pad; segI[nI + lane] = DEP_NULL | ((uint32_t)x0c + TS_BIAS);
         }
 #define TS_SWEEP(SEG4, N, MODE, ACC) { \
         uint4 q = SEG4[0]; \
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         TS_SWEEP(segF4, nF, 1, accF)
 #undef TS_SWEEP
 #pragma unroll 1
-        for (int i = 0; i < (nI + 3) >> 2; ++i) fu_group<2, TAB_LDS, RS>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
+        for (int i = 0; i < (nI + 3) >> 2; ++i) ts_image_group<TAB_LDS, RS>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
 #ifdef APS_STAMPS
         f_n += nP + nM + nF + nI;
 #endif
@@ -375,18 +404,25 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         cnt = min(cnt, (uint32_t)a.dcap);
         // NSLOT slots of each of the wave's buckets: compact the valid ones into the wave's segments by class.  Near a
         // reflecting wall the deposits with an image in reach go to the (untyped) image segment.
-#define TS_PUT(SEGX, NX, COND) { const unsigned long long m_ = __ballot(COND); \
-            if (COND) SEGX[NX + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u))] = en_; \
+#define TS_PUT(SEGX, NX, COND, WORD) { const unsigned long long m_ = __ballot(COND); \
+            if (COND) SEGX[NX + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u))] = (WORD); \
             NX += __popcll(m_); }
+#define TS_FULL() (nP + 64 > SEG - 4 || nM + 64 > SEG - 4 || nF + 64 > SEG - 4 || nI + 64 > SEG - 4)
 #define TS_ROUND(EN, K0) { \
-            const uint32_t en_ = (EN); \
+            const uint32_t en_ = (EN) + TS_BIAS;               /* site field biased (no carry: sites < 2^25) */ \
             const bool valid = (K0) + slot < cnt; \
-            const int dp = (int)(en_ & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2; \
-            const bool img = valid && wall && ((x0c + dp + 1 <= Rt) || (2 * L - 1 - x1c - dp <= Rt)); \
-            const bool pl = valid && !img; \
-            if (nP + 64 > SEG - 4 || nM + 64 > SEG - 4 || nF + 64 > SEG - 4 || nI + 64 > SEG - 4) flush(); \
-            TS_PUT(segP, nP, (pl && cw != 0 && cw == cs)) TS_PUT(segM, nM, (pl && cw != 0 && cw != cs)) TS_PUT(segF, nF, (pl && cw == 0)) \
-            if (wall) TS_PUT(segI, nI, img) }
+            const int dp = (int)((EN) & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2; \
+            const bool img_l = valid && wall && (x0c + dp + 1 <= Rt), img_r = valid && wall && (2 * L - 1 - x1c - dp <= Rt); \
+            const bool cP = cw != 0 && cw == cs, cM = cw != 0 && cw != cs, cF = cw == 0; \
+            const bool pl = valid && (mirror_ok || !(img_l || img_r)); \
+            if (TS_FULL()) flush(); \
+            TS_PUT(segP, nP, (pl && cP), en_) TS_PUT(segM, nM, (pl && cM), en_) TS_PUT(segF, nF, (pl && cF), en_) \
+            if (wall && mirror_ok) {                           /* the wall image of a deposit = the same deposit at the mirrored site */ \
+                const bool im = img_l || img_r; \
+                const uint32_t mir = (en_ & ~POS_MASK) | (uint32_t)((int)TS_BIAS + (img_l ? -1 - dp : 2 * L - 1 - dp)); \
+                if (TS_FULL()) flush(); \
+                TS_PUT(segP, nP, (im && cP), mir) TS_PUT(segM, nM, (im && cM), mir) TS_PUT(segF, nF, (im && cF), mir) \
+            } else if (wall) TS_PUT(segI, nI, (valid && (img_l || img_r)), en_) }
         if (TAB_LDS) {
             for (uint32_t k0 = 0;; k0 += NSLOT) {
                 TS_ROUND(ent, k0)
@@ -401,6 +437,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             }
         }
 #undef TS_ROUND
+#undef TS_FULL
 #undef TS_PUT
         if (!TAB_LDS && windowed) { TSTAMP(f_copy) flush(); TSTAMP(f_proc) }
     }
