@@ -1700,7 +1700,7 @@ void ts_choose_geometry(aps_handle *h) {
         h->ts_RS = ts_lds_layout(h->tlen, true, 4, 252, h->p.K).total <= 160 * 1024 ? 4 : 6;
     if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
     h->ts_own = 64 * h->ts_RS - 4;
-    if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 1 && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
+    if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
     h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K).total <= 160 * 1024;
@@ -1958,7 +1958,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
         (rc = dev_alloc(h, &h->d_plan, (size_t)h->E * h->ntiles * PLAN_CAP)) || (rc = dev_alloc(h, &h->d_plan_n, (size_t)h->E * h->ntiles)) ||
         (rc = dev_alloc(h, &h->d_accW, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_accS, EN * MAX_SPLIT)) ||
         (rc = dev_alloc(h, &h->d_occ, EN * MAX_SPLIT)) || (rc = dev_alloc(h, &h->d_pcnt, 2 * EL)) ||
-        (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size() + ((size_t)1 << h->bshift) + 1024)) ||
+        (rc = dev_alloc(h, &h->d_plist, EL * 2 * p->K)) || (rc = dev_alloc(h, &h->d_table, h->table.size() + ((size_t)1 << h->bshift) + 8192))   /* zeros behind the table: windows and LDS staging run past its end */ ||
         (rc = dev_alloc(h, &h->d_beta, (size_t)h->E)) || (rc = dev_alloc(h, &h->d_gsum, (size_t)4 * h->E)) ||
         (rc = dev_alloc(h, &h->d_exit, (size_t)h->E * h->exit_cap * 3)) || (rc = dev_alloc(h, &h->d_nexit, (size_t)h->E)) ||
         (rc = dev_alloc(h, &h->d_mfield, (size_t)p->L)))

@@ -48,7 +48,9 @@ template <bool TAB_LDS> struct TsGeom { static constexpr int SB = TAB_LDS ? 4 : 
 
 __host__ __device__ inline int ts_table_pad(int RS, int own) { return 64 * RS + own + 2; }
 __host__ __device__ inline int ts_table_chunks(int tlen, int RS, int own) { return (tlen + ts_table_pad(RS, own) + 1 + 127) / 128; }   // 1 KB each
-__host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TsGeom<false>::GB * own) + 64 * RS + 8 + 127) / 128 * 128; }
+constexpr int TS_WH = 8;                   // windowed sweep: bucket offsets per group (buckets tile - off and tile + off, off in [jH, jH + H))
+__host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TS_WH + 1) * own + 64 * RS + 8 + 127) / 128 * 128; }
+constexpr int TS_SHCAP = 320;              // windowed sweep: capacity of a shared class list (a round adds at most 256 entries)
 constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
 struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
 __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K) {
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     if (!a.field_mode) {
         for (int i = t; i < a.ntile; i += FU_THREADS) { gS += a.gpart_in[((size_t)e * a.ntile + i) * 2]; gN += a.gpart_in[((size_t)e * a.ntile + i) * 2 + 1]; }
     }
-    if (t < 8) misc[t] = 0;
+    if (t < 16) misc[t] = 0;
     for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;   // EV_NONE everywhere
     // this wave's particles and their random numbers
     int n_w = 0;
@@ -319,24 +321,9 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     // ---------------------------------------------------------------- 1  deposits of the previous step -> W, S of the frame
     const bool windowed = !TAB_LDS && BC == 0 && !wall;
     const uint32_t tb = TAB_LDS ? tbase : 0u;                  // table in global memory: byte offsets from its start
-    uint32_t win_base = tbase;
     const uint32_t win_lds = tbase;
     const int WIN = ts_win_entries(RS, OWN);
-    int null_site = x0c;
-    int dmin_next = 0, null_next = x0c;
-    auto stage = [&](int j) {                                  // request window j into buffer j & 1 (see field_update)
-        const int bs = b0 + j * GB, be = min(bs + GB, b0 + nbk);
-        const int sA = max(0, bs * OWN - 1), sB = min(L - 1, be * OWN);
-        const int dmin = max(0, max(x0c - sB, sA - x1c)), dmax = max(x1c - sA, sB - x0c), span = dmax - dmin;
-        const double *srcw = table_g + dmin + lane * 2;
-        const uint32_t dstw = win_lds + (uint32_t)((j & 1) * WIN) * 8u;
-        for (int c = wave; c * 128 <= span; c += FU_WAVES) {
-            const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dstw + (uint32_t)c * 1024u));
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srcw + c * 128) : "memory");
-        }
-        dmin_next = dmin;
-        null_next = min(max(x0c, sA), sB);
-    };
+    const int null_site = x0c;
     int nP = 0, nM = 0, nF = 0, nI = 0;                        // entries waiting in this wave's four segments
     const uint4 *segP4 = reinterpret_cast<const uint4 *>(segP), *segM4 = reinterpret_cast<const uint4 *>(segM),
                 *segF4 = reinterpret_cast<const uint4 *>(segF), *segI4 = reinterpret_cast<const uint4 *>(segI);
@@ -350,7 +337,6 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         _Pragma("unroll 1") for (int i = 0; i < ((N) + 3) >> 2; ++i) { \
             const uint4 qn = SEG4[i + 1];                      /* next group's entries: in flight during this group's gathers */ \
             if (BC == 1) ts_group<1, TAB_LDS, RS, MODE>(q, x8, tb, table_g, tlen8, L8, ACC); \
-            else if (!TAB_LDS && windowed) ts_group<0, true, RS, MODE>(q, x8, win_base, table_g, tlen8, L8, ACC); \
             else ts_group<0, TAB_LDS, RS, MODE>(q, x8, tb, table_g, tlen8, L8, ACC); \
             q = qn; } }
         TS_SWEEP(segP4, nP, 0, accP)
@@ -365,8 +351,117 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         nP = nM = nF = nI = 0;
     };
     const int ngroups = (nbk + GB - 1) / GB;
-    if (!TAB_LDS && windowed && ngroups > 0) stage(0);
-    uint32_t nx_cnt = 0u, nx_ent = DEP_NULL;
+    if (!TAB_LDS && windowed) {
+        // Table beyond LDS, interior tile.  The buckets at offsets -off and +off from this tile are at the same distances,
+        // so they share one window of the table: group j = offsets [jH, jH + H) on both sides (16 buckets x 16 list slots =
+        // one load per lane).  The four waves pool a group's deposits into SHARED per-class lists (one LDS atomic per wave),
+        // and every wave then takes whole groups of four from those lists: no per-wave padding, half the barriers.
+        // Window j (distances [(jH - 1) OWN - 2, (jH + H) OWN + 2]) is double buffered and requested one group ahead by
+        // LDS-direct loads; list words likewise.  Shared lists: double buffered; their packed lengths: triple buffered.
+        constexpr int H = TS_WH;
+        uint32_t *shl = seg_all;                               // [2][3][TS_SHCAP], over the per-wave segments (unused here)
+        int *scnt = misc + 8;                                  // [3][2]: lengths nP | nM << 10 | nF << 20, "a bucket has more than 16" flag
+        const int side = max(tile - b0, b0 + nbk - 1 - tile);
+        const int ngr = side / H + 1;
+        const int bsel = (lane >> 4) * FU_WAVES + wave, sl16 = lane & 15;
+        const unsigned sl16c = (unsigned)min(sl16, a.dcap - 1);
+        auto bucket_of = [&](int j, bool &okb) -> int {
+            const int off = j * H + (bsel >> 1);
+            const bool neg = (bsel & 1) != 0;
+            const int b = neg ? tile - off : tile + off;
+            okb = off <= side && !(neg && off == 0) && b >= b0 && b < b0 + nbk;
+            return okb ? b : tile;
+        };
+        // distances of the frame to the deposits of buckets tile +- off, off in [jH, jH + H) (deposit sites lie within one site of their bucket)
+        auto win_dmin = [&](int j) -> int { return max(0, min((j * H - 1) * OWN - 2, j * H * OWN + 2 - TS)); };
+        auto stage_w = [&](int j) {
+            const int dmin = win_dmin(j), span = max((j * H + H) * OWN + 2, (j * H + H - 1) * OWN + TS - 2) - dmin;
+            const double *srcw = table_g + dmin + lane * 2;
+            const uint32_t dstw = win_lds + (uint32_t)((j & 1) * WIN) * 8u;
+            for (int c = wave; c * 128 <= span; c += FU_WAVES) {
+                const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dstw + (uint32_t)c * 1024u));
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srcw + c * 128) : "memory");
+            }
+        };
+        stage_w(0);
+        bool okb;
+        int b = bucket_of(0, okb);
+        uint32_t cnt = dcnt_e[(unsigned)b], ent = dep_e[(unsigned)b * (unsigned)a.dcap + sl16c];
+        if (!okb) cnt = 0u;
+        for (int j = 0; j < ngr; ++j) {
+            TSTAMP(f_copy)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's chunks of window j and its list words have landed
+            asm volatile("" : "+v"(cnt), "+v"(ent));
+            cnt = min(cnt, (uint32_t)a.dcap);
+            const int jj = j & 1, j3 = j % 3;
+            {   // pool this wave's entries of group j
+                const uint32_t en_ = ent + TS_BIAS;
+                const bool valid = (uint32_t)sl16 < cnt;
+                const int cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2;
+                const bool cP = valid && cw != 0 && cw == cs, cM = valid && cw != 0 && cw != cs, cF = valid && cw == 0;
+                const unsigned long long mP = __ballot(cP), mM = __ballot(cM), mF = __ballot(cF);
+                const int add = __popcll(mP) | (__popcll(mM) << 10) | (__popcll(mF) << 20);
+                int base = 0;
+                if (lane == 0 && add) base = atomicAdd(&scnt[j3 * 2], add);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (__ballot((uint32_t)sl16 + 16u <= cnt && cnt > 16u) && lane == 0) atomicOr(&scnt[j3 * 2 + 1], 1);
+                uint32_t *lst = shl + (size_t)jj * 3 * TS_SHCAP;
+#define TS_POOL(COND, MASK, SHIFT, CLS) if (COND) lst[(CLS) * TS_SHCAP + ((base >> (SHIFT)) & 1023) + \
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)((MASK) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(MASK), 0u))] = en_;
+                TS_POOL(cP, mP, 0, 0) TS_POOL(cM, mM, 10, 1) TS_POOL(cF, mF, 20, 2)
+#undef TS_POOL
+            }
+            __syncthreads();                                   // lists j complete, window j landed everywhere, everyone is done with group j - 1
+            if (t == 0) { scnt[((j + 2) % 3) * 2] = 0; scnt[((j + 2) % 3) * 2 + 1] = 0; }   // nobody touches that pair before the next barrier
+            const uint32_t wbase = win_lds + (uint32_t)(jj * WIN) * 8u - ((uint32_t)win_dmin(j) << 3);
+            const uint32_t padw = DEP_NULL | ((uint32_t)(j == 0 ? x0c : x1c + win_dmin(j)) + TS_BIAS);
+            const uint32_t cnt_now = cnt;
+            const int b_now = b;
+            if (j + 1 < ngr) {                                 // next window and next list words: in flight during this sweep
+                stage_w(j + 1);
+                b = bucket_of(j + 1, okb);
+                cnt = dcnt_e[(unsigned)b]; ent = dep_e[(unsigned)b * (unsigned)a.dcap + sl16c];
+                if (!okb) cnt = 0u;
+            }
+            TSTAMP(f_cnt)
+            const int packed = scnt[j3 * 2], more = scnt[j3 * 2 + 1];
+            const int nn[3] = {packed & 1023, (packed >> 10) & 1023, (packed >> 20) & 1023};
+            int rot = wave;                                    // whole groups of four are dealt round-robin across the classes
+#define TS_SHARED(CLS, MODE, ACC) { \
+                const int n_ = nn[CLS], ng_ = (n_ + 3) >> 2; \
+                const uint4 *l4 = reinterpret_cast<const uint4 *>(shl + ((size_t)jj * 3 + (CLS)) * TS_SHCAP); \
+                int g = rot & 3; \
+                uint4 q = l4[min(g, TS_SHCAP / 4 - 1)]; \
+                _Pragma("unroll 1") for (; g < ng_; g += FU_WAVES) { \
+                    const uint4 qn = l4[min(g + FU_WAVES, TS_SHCAP / 4 - 1)]; \
+                    const int left = n_ - 4 * g;               /* entries beyond the list's end -> padding */ \
+                    q.y = left > 1 ? q.y : padw; q.z = left > 2 ? q.z : padw; q.w = left > 3 ? q.w : padw; \
+                    ts_group<0, true, RS, MODE>(q, x8, wbase, table_g, tlen8, L8, ACC); \
+                    q = qn; } \
+                rot = (rot - ng_) & 3; }
+            TS_SHARED(0, 0, accP) TS_SHARED(1, 0, accM) TS_SHARED(2, 1, accF)
+#undef TS_SHARED
+            if (more) {                                        // rare: a bucket of this group holds more than 16 deposits -> one by one
+                for (uint32_t k0 = 16; __ballot(k0 < cnt_now); k0 += 16) {
+                    const bool valid = k0 + (uint32_t)sl16 < cnt_now;
+                    const uint32_t en = dep_e[(unsigned)b_now * (unsigned)a.dcap + min(k0 + (uint32_t)sl16, (uint32_t)a.dcap - 1u)] + TS_BIAS;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also waits for the next window: harmless here)
+                    unsigned long long mm = __ballot(valid);
+                    while (mm) {
+                        const int src_lane = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)en, src_lane);
+                        const uint4 q1 = make_uint4(e1, padw, padw, padw);
+                        const int cw = (int)((e1 >> 27) & 3u) - 1, cs = (int)(e1 >> 29) - 2;
+                        if (cw == 0) ts_group<0, true, RS, 1>(q1, x8, wbase, table_g, tlen8, L8, accF);
+                        else if (cw == cs) ts_group<0, true, RS, 0>(q1, x8, wbase, table_g, tlen8, L8, accP);
+                        else ts_group<0, true, RS, 0>(q1, x8, wbase, table_g, tlen8, L8, accM);
+                    }
+                }
+            }
+            TSTAMP(f_proc)
+        }
+    } else {
     for (int j = 0; j < ngroups; ++j) {
         const int bi = j * GB + sub * FU_WAVES + wave;
         const bool ok = bi < nbk;
@@ -374,36 +469,14 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         if (b >= a.ntile) b -= a.ntile;
         uint32_t cnt, ent;
         if (j < FU_PRE) { cnt = j == 0 ? pre_cnt[0] : pre_cnt[FU_PRE - 1]; ent = j == 0 ? pre_ent[0] : pre_ent[FU_PRE - 1]; }
-        else if (!TAB_LDS) { cnt = nx_cnt; ent = nx_ent; }
         else {
             cnt = dcnt_e[(unsigned)b];
             ent = dep_e[(unsigned)b * (unsigned)a.dcap + slot_c];
             if (!ok) cnt = 0u;
         }
-        if (!TAB_LDS) {
-            TSTAMP(f_copy)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(cnt), "+v"(ent));
-        }
-        if (!TAB_LDS && windowed) {
-            __syncthreads();
-            win_base = win_lds + (uint32_t)((j & 1) * WIN) * 8u - ((uint32_t)dmin_next << 3);
-            null_site = null_next;
-            if (j + 1 < ngroups) stage(j + 1);
-            TSTAMP(f_cnt)
-        }
-        if (!TAB_LDS && j + 1 >= FU_PRE && j + 1 < ngroups) {
-            const int bi1 = (j + 1) * GB + sub * FU_WAVES + wave;
-            const bool ok1 = bi1 < nbk;
-            int b1 = b0 + (ok1 ? bi1 : 0);
-            if (b1 >= a.ntile) b1 -= a.ntile;
-            nx_cnt = dcnt_e[(unsigned)b1];
-            nx_ent = dep_e[(unsigned)b1 * (unsigned)a.dcap + slot_c];
-            if (!ok1) nx_cnt = 0u;
-        }
         cnt = min(cnt, (uint32_t)a.dcap);
         // NSLOT slots of each of the wave's buckets: compact the valid ones into the wave's segments by class.  Near a
-        // reflecting wall the deposits with an image in reach go to the (untyped) image segment.
+        // reflecting wall the image of a deposit is the same deposit at the mirrored site (small boxes: image segment).
 #define TS_PUT(SEGX, NX, COND, WORD) { const unsigned long long m_ = __ballot(COND); \
             if (COND) SEGX[NX + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u))] = (WORD); \
             NX += __popcll(m_); }
@@ -417,32 +490,24 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             const bool pl = valid && (mirror_ok || !(img_l || img_r)); \
             if (TS_FULL()) flush(); \
             TS_PUT(segP, nP, (pl && cP), en_) TS_PUT(segM, nM, (pl && cM), en_) TS_PUT(segF, nF, (pl && cF), en_) \
-            if (wall && mirror_ok) {                           /* the wall image of a deposit = the same deposit at the mirrored site */ \
+            if (wall && mirror_ok) { \
                 const bool im = img_l || img_r; \
                 const uint32_t mir = (en_ & ~POS_MASK) | (uint32_t)((int)TS_BIAS + (img_l ? -1 - dp : 2 * L - 1 - dp)); \
                 if (TS_FULL()) flush(); \
                 TS_PUT(segP, nP, (im && cP), mir) TS_PUT(segM, nM, (im && cM), mir) TS_PUT(segF, nF, (im && cF), mir) \
             } else if (wall) TS_PUT(segI, nI, (valid && (img_l || img_r)), en_) }
-        if (TAB_LDS) {
-            for (uint32_t k0 = 0;; k0 += NSLOT) {
-                TS_ROUND(ent, k0)
-                if (!__ballot(k0 + NSLOT < cnt)) break;
-                ent = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + NSLOT + slot, (uint32_t)a.dcap - 1u)];
-            }
-        } else {
-            TS_ROUND(ent, 0u)
-            for (uint32_t k0 = NSLOT; __ballot(k0 < cnt); k0 += NSLOT) {
-                const uint32_t en = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + slot, (uint32_t)a.dcap - 1u)];
-                TS_ROUND(en, k0)
-            }
+        for (uint32_t k0 = 0;; k0 += NSLOT) {
+            TS_ROUND(ent, k0)
+            if (!__ballot(k0 + NSLOT < cnt)) break;
+            ent = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + NSLOT + slot, (uint32_t)a.dcap - 1u)];
         }
 #undef TS_ROUND
 #undef TS_FULL
 #undef TS_PUT
-        if (!TAB_LDS && windowed) { TSTAMP(f_copy) flush(); TSTAMP(f_proc) }
+    }
     }
     TSTAMP(f_copy)
-    flush();
+    if (TAB_LDS || !windowed) flush();                         // (the shared lists of the windowed sweep live in the segments' space)
     TSTAMP(f_proc)
     __syncthreads();                                           // every wave is done with the table: its space takes the partial sums
 #pragma unroll
