@@ -1685,7 +1685,7 @@ constexpr int TS_RS_CHOICES[] = {1, 2, 3, 4, 5, 6, 7, 8};
 
 // tile geometry (measured on MI355X, profiles/r02_*): while the whole grid is resident at once (<= 3 workgroups per CU)
 // the frame that gives about 2.4 workgroups per CU is fastest (64 * 5 sites at L = 2e5); larger grids run in waves of
-// workgroups and want the frame with the best work per instruction: 256 sites with the table in LDS, 384 with windows
+// workgroups and want the frame with the best work per instruction and three resident workgroups per CU: 256 sites
 void ts_choose_geometry(aps_handle *h) {
     const int L = h->p.L;
     h->ts_RS = 1;
@@ -1697,7 +1697,7 @@ void ts_choose_geometry(aps_handle *h) {
         if (miss < best) { best = miss; h->ts_RS = rs; }
     }
     if ((double)(((int64_t)L + 507) / 508) * h->E > 3.0 * 256.0)      // even the largest frame leaves more than 3 per CU
-        h->ts_RS = ts_lds_layout(h->tlen, true, 4, 252, h->p.K).total <= 160 * 1024 ? 4 : 6;
+        h->ts_RS = 4;
     if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
     h->ts_own = 64 * h->ts_RS - 4;
     if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
