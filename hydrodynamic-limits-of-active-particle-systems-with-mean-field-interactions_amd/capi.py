@@ -110,6 +110,7 @@ def load():
         "aps_observe_scalars": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
         "aps_observe_scalars_all": (C.c_int, [vp, i32, vp, vp, vp]),
         "aps_event_overhead": (C.c_int, [vp, i32, P(dbl)]),
+        "aps_observe_structure": (C.c_int, [vp, i32, i32, vp]),
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
@@ -291,6 +292,13 @@ class Handle:
         rng = None if ranges is None else np.ascontiguousarray(ranges, dtype=np.int32).reshape(self.E, 2)
         self._ck(self.lib.aps_observe_scalars_all(self._h, int(x_wall), _ptr(rng), _ptr(tab), _ptr(out)))
         return [{k: int(v) for k, v in zip(self.SCALARS, row)} for row in out]
+
+    def observe_structure(self, ensemble=0, k_max=25):
+        """(n live, sum count^2 over sites, sum m, sum m^2 over sites, [k_max][2] Fourier sums of the site histogram)."""
+        k_max = int(min(k_max, self.L))
+        out = np.zeros(4 + 2 * k_max)
+        self._ck(self.lib.aps_observe_structure(self._h, ensemble, k_max, _ptr(out)))
+        return int(out[0]), float(out[1]), float(out[2]), float(out[3]), out[4:].reshape(k_max, 2)
 
     # -- observation
     def observe(self, ensemble=0, want_field=True):

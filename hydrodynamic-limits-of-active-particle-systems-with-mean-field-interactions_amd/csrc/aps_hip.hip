@@ -1246,6 +1246,43 @@ __global__ __launch_bounds__(256) void tile_parts(const uint32_t *__restrict__ c
     }
 }
 
+// ---- structure observables on the device (extract_structure_observables_from_out, PARTICLE_solver_BIOLOGY_local_structure.py:55-103)
+// per-site sums: sum over sites of (count_plus + count_minus)^2, of the local magnetisation and of its square
+__global__ __launch_bounds__(256) void structure_sites(const uint32_t *__restrict__ cnt_pm, const double *__restrict__ m_field, int L, double *out) {
+    double c2 = 0.0, m1 = 0.0, m2 = 0.0;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < L; x += gridDim.x * blockDim.x) {
+        const uint32_t c = cnt_pm[x];
+        const double tot = (double)((c & 0xFFFFu) + (c >> 16)), m = m_field[x];
+        c2 += tot * tot; m1 += m; m2 += m * m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c2 += __shfl_xor(c2, off); m1 += __shfl_xor(m1, off); m2 += __shfl_xor(m2, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[1], c2); atomicAdd(&out[2], m1); atomicAdd(&out[3], m2); }
+}
+
+// Fourier sums of the site histogram, one workgroup per mode k: sum over live particles of exp(-2 pi i k pos / L)
+// (= fft(counts)[k], the reference's np.fft.fft(total) up to the 1 / (n dx) normalisation, ref :527-533)
+__global__ __launch_bounds__(256) void structure_dft(const uint32_t *__restrict__ src, int Npad, int L, double *out) {
+    const int k = blockIdx.x;
+    double re = 0.0, im = 0.0, n = 0.0;
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+        const uint32_t w = src[i];
+        if (w & DEAD_BIT) continue;
+        const long long r = ((long long)k * (long long)(w & POS_MASK)) % (long long)L;   // exact argument reduction
+        double sn, cs;
+        sincospi(-2.0 * ((double)r / (double)L), &sn, &cs);
+        re += cs; im += sn; n += 1.0;
+    }
+    __shared__ double acc[3];
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { re += __shfl_xor(re, off); im += __shfl_xor(im, off); n += __shfl_xor(n, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], re); atomicAdd(&acc[1], im); atomicAdd(&acc[2], n); }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[4 + 2 * k] = acc[0]; out[5 + 2 * k] = acc[1]; if (k == 0) out[0] = acc[2]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 std::string g_create_error;
 
@@ -2351,7 +2388,8 @@ int observe_scalars_impl(aps_handle *h, int e0, int n, int32_t x_wall, const int
     const int K = h->p.K, L = h->p.L;
     int rc;
     if ((rc = sync_slots(h))) return rc;
-    if (!h->d_scal && ((rc = dev_alloc(h, &h->d_scal, (size_t)16 * h->E)) || (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L * h->E)) ||
+    if (!h->d_cnt_pm && (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L * h->E))) return rc;
+    if (!h->d_scal && ((rc = dev_alloc(h, &h->d_scal, (size_t)16 * h->E)) ||
                        (rc = dev_alloc(h, &h->d_block_table, (size_t)(K + 1) * (K + 1))) || (rc = dev_alloc(h, &h->d_lo_hi, (size_t)2 * h->E)) ||
                        (rc = dev_alloc(h, &h->d_ref_ok, (size_t)h->E)))) return rc;
     std::vector<uint8_t> table((size_t)(K + 1) * (K + 1), 0);
@@ -2398,6 +2436,30 @@ int aps_observe_scalars_all(aps_handle *h, int32_t x_wall, const int32_t *range_
     if (!out11) return fail(h, APS_ERR_ARG, "aps_observe_scalars_all: bad argument");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_observe_scalars_all: upload a state for every ensemble first");
     return observe_scalars_impl(h, 0, h->E, x_wall, range_lo_hi, 0, -1, block_table, out11);
+}
+
+int aps_observe_structure(aps_handle *h, int32_t e, int32_t k_max, double *out) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !out || k_max < 1 || k_max > h->p.L) return fail(h, APS_ERR_ARG, "aps_observe_structure: bad argument");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_observe_structure: no state uploaded for this ensemble");
+    int rc = sync_slots(h);
+    if (rc) return rc;
+    const int L = h->p.L;
+    const size_t nout = 4 + 2 * (size_t)k_max;
+    if (!h->d_cnt_pm && (rc = dev_alloc(h, &h->d_cnt_pm, (size_t)L * h->E))) return rc;
+    double *d_out = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&d_out), nout * sizeof(double)));
+    auto done = [&](int code) { (void)hipFree(d_out); return code; };
+    if (hipMemsetAsync(d_out, 0, nout * sizeof(double), h->stream) != hipSuccess ||
+        hipMemsetAsync(h->d_cnt_pm, 0, (size_t)L * 4, h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_structure: memset failed"));
+    const uint32_t *src = h->d_src + (size_t)e * h->Npad;
+    hipLaunchKernelGGL(count_sites, dim3((unsigned)(h->Npad / 256), 1u), dim3(256), 0, h->stream, src, h->d_cnt_pm, (int)h->Npad, L);
+    if ((rc = launch_field(h, e, h->d_sp8 + (size_t)e * h->Npad, h->d_tinfo + (size_t)e * h->ntiles, (int)h->ntiles, h->d_mfield))) return done(rc);
+    hipLaunchKernelGGL(structure_sites, dim3((unsigned)std::min(1024, (L + 255) / 256)), dim3(256), 0, h->stream, h->d_cnt_pm, h->d_mfield, L, d_out);
+    hipLaunchKernelGGL(structure_dft, dim3((unsigned)k_max), dim3(256), 0, h->stream, src, (int)h->Npad, L, d_out);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_structure: kernel or copy failed"));
+    return done(APS_OK);
 }
 
 int aps_method(aps_handle *h) { return h ? h->method : APS_ERR_ARG; }

@@ -8,7 +8,8 @@ dictionary of `ParticleSystem.run`.  Reference map (file = PARTICLE_solver_BIOLO
     mean_magnetisation       <- compute_mean_magnetizatoin    :316-319
     active_diffusivity       <- compute_D_eff_active          :500-525
     ensemble_statistics      <- the reduction at the end of sweep_beta_ensemble :97-117
-Pinned by fixture tests/golden/g7_observables.npz (generated from the reference's own functions).
+    structure_observables    <- extract_structure_observables_from_out of PARTICLE_solver_BIOLOGY_local_structure.py:55-103
+Pinned by fixtures tests/golden/g7_observables.npz and g10_structure.npz (generated from the reference's own functions).
 """
 from __future__ import annotations
 
@@ -184,3 +185,64 @@ class DeviceObservables:
         return dict(v=float(np.mean(v_ts[start:end])), D=float(D), m=float(np.mean(m_glob[start:end])),
                     rho=float(np.mean(fronts)) if fronts else float("nan"), block=float(blk / att) if att else 0.0,
                     window=(start, end), v_ts=v_ts, frac_boundary=frac_boundary, m_global=m_glob)
+
+
+# ------------------------------------------------------------------------------------------------ structure observables
+def structure_observables(out, start_fraction=0.5, k_max=None):
+    """Pattern / clustering observables of a run made with record_fft=True, record_var=True
+    (PARTICLE_solver_BIOLOGY_local_structure.py:55-103): time mean and spread of var(total) and of the Fourier
+    amplitudes |fft(total)| over the steady-state window [start_fraction * M, M), the dominant non-zero mode, the summed
+    low-k amplitudes (k = 1..24), the variance of the local magnetisation over window x lattice and the mean low-k power."""
+    M = len(out["times_obs"])
+    start = int(start_fraction * M)
+    var_ts = np.asarray(out["var_list"], dtype=float)[start:]
+    amp = np.asarray(out["fft_amp_list"], dtype=float)
+    if k_max is not None:
+        amp = amp[:, :k_max]
+    ss = amp[start:]
+    fft_mean, fft_std = ss.mean(axis=0), ss.std(axis=0, ddof=1)
+    cut = min(25, amp.shape[1])
+    m_ss = np.asarray(out["m_local_list"], dtype=float)[start:]
+    return {"var_mean": var_ts.mean(), "var_std": var_ts.std(ddof=1), "fft_mean": fft_mean, "fft_std": fft_std,
+            "dominant_k": int(np.argmax(fft_mean[1:]) + 1), "low_k_power": float(np.sum(fft_mean[1:cut])),
+            "m_local_var": float(np.var(m_ss)), "lowk_variance": float(np.mean(np.sum(ss[:, 1:cut] ** 2, axis=1)))}
+
+
+extract_structure_observables_from_out = structure_observables      # the reference's name
+
+
+class DeviceStructure:
+    """The same eight observables accumulated from what the GPU returns per observation (aps_observe_structure): the live
+    particle number n, sum over sites of count^2, sum and sum of squares of the local magnetisation over the L sites, and the
+    first k_max Fourier sums of the site histogram.  Nothing of size M x L ever leaves the device.
+
+    total = count / (n dx) (ref :205-213), so var(total) = (sum c^2 / L - (n / L)^2) / (n dx)^2 and
+    |fft(total)|_k = |sum_x c_x exp(-2 pi i k x / L)| / (n dx)."""
+
+    def __init__(self, n_obs, L, dx, start_fraction=0.5, k_max=None):
+        self.M, self.L, self.dx = int(n_obs), int(L), float(dx)
+        self.start = int(start_fraction * self.M)
+        self.k_max = self.L if k_max is None else min(int(k_max), self.L)
+        self.var, self.amp, self.m1, self.m2 = [], [], 0.0, 0.0
+        self.nm = 0
+
+    def add(self, k, n_live, sum_c2, sum_m, sum_m2, re_im):
+        if k < self.start:
+            return
+        L, nd = self.L, float(n_live) * self.dx
+        self.var.append((sum_c2 / L - (n_live / L) ** 2) / (nd * nd) if n_live else np.nan)
+        z = np.asarray(re_im, dtype=float).reshape(-1, 2)
+        self.amp.append(np.hypot(z[:, 0], z[:, 1]) / nd if n_live else np.full(len(z), np.nan))
+        self.m1 += sum_m
+        self.m2 += sum_m2
+        self.nm += L
+
+    def result(self):
+        var, amp = np.array(self.var), np.array(self.amp)
+        fft_mean, fft_std = amp.mean(axis=0), amp.std(axis=0, ddof=1)
+        cut = min(25, amp.shape[1])
+        mean_m = self.m1 / self.nm
+        return {"var_mean": var.mean(), "var_std": var.std(ddof=1), "fft_mean": fft_mean, "fft_std": fft_std,
+                "dominant_k": int(np.argmax(fft_mean[1:]) + 1), "low_k_power": float(np.sum(fft_mean[1:cut])),
+                "m_local_var": float(self.m2 / self.nm - mean_m * mean_m),
+                "lowk_variance": float(np.mean(np.sum(amp[:, 1:cut] ** 2, axis=1)))}

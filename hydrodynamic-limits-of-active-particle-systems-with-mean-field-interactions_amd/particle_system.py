@@ -7,7 +7,8 @@ Differences that are part of the design:
     `dt` defaults to 0.1 / (largest possible total rate of one particle);
   * randomness inside `run` comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng.random()` right
     after the initial condition, so a seeded `rng` still makes the whole run reproducible);
-  * `flip_rate_fn` must stay None (the Curie-Weiss rate exp(-beta*sigma*m) is evaluated on the GPU);
+  * a custom `flip_rate_fn` (a Python callable) is honoured by `mode="gillespie"` only; the device modes evaluate the
+    Curie-Weiss rate exp(-beta*sigma*m) themselves and refuse a callable;
   * `mode="gillespie"` (or calling `step_gillespie` yourself) runs the reference's exact one-event-per-iteration
     loop instead, with the m-field and the rate vectors of every event computed on the GPU and the event drawn
     from `rng` in the reference's call order.
@@ -45,10 +46,9 @@ class ParticleSystem:
         self.k_on, self.k_off, self.k_exit = k_on, k_off, k_exit
         self.suppress_flip_when_bound = suppress_flip_when_bound
         self.crowding_suppresses_rates = crowding_suppresses_rates
-        if flip_rate_fn is not None:
-            raise NotImplementedError(
-                "flip_rate_fn: only the default Curie-Weiss rate exp(-beta*sigma*m) runs on the GPU path")
-        self.flip_rate_fn = None
+        # a custom flip rate (ref :59-62, applied at :261-262) is an arbitrary Python callable: it runs on the host, inside
+        # the exact one-event-per-iteration loop (mode="gillespie"), where the other five rate channels still come from the GPU
+        self.flip_rate_fn = flip_rate_fn
         assert init in ("fixed", "poisson")
         self.init_mode = init
         if init == "fixed":
@@ -88,6 +88,11 @@ class ParticleSystem:
             raise ValueError("mode must be 'sync' (fixed-dt stepper), 'gillespie' (one exact event per iteration, drawn "
                              "from rng on the host) or 'gillespie_gpu' (the exact event loop resident on the GPU)")
         self.mode = mode
+        if flip_rate_fn is not None and mode != "gillespie":
+            raise NotImplementedError(
+                f"flip_rate_fn is a host callable: it is supported by mode='gillespie' (the reference's exact event loop, "
+                f"rates of the other channels from the GPU); mode={mode!r} evaluates the Curie-Weiss rate exp(-beta*sigma*m) "
+                f"on the device and cannot call back into Python")
         if method not in capi.METHODS:
             raise ValueError("method must be 'auto', 'pairs' (all-pairs kernel) or 'lattice' (incremental lattice field)")
         self.method = method
@@ -180,6 +185,12 @@ class ParticleSystem:
         if n == 0:
             return pos, sigma, bound, np.inf, counts_p, counts_m
         rt = self._utility_handle().rates_from_field(pos, sigma, bound, m_field, counts_p, counts_m)
+        if self.flip_rate_fn is not None:                          # ref :261-267, then the sum of :351 in its order
+            cvec = np.asarray(self.flip_rate_fn(sigma, m_field[pos]), dtype=float).copy()
+            if self.suppress_flip_when_bound:
+                cvec[np.asarray(bound, dtype=bool)] = 0.0
+            rt["flip"] = cvec
+            rt["total"] = ((((rt["diff"] + rt["act"]) + cvec) + rt["bind"]) + rt["unbind"]) + rt["exit"]
         rates = rt["total"]
         R = float(rates.sum())
         if R <= 0:
@@ -453,6 +464,49 @@ def run_batched_statistics(systems, T=10.0, obs_dt=0.01):
                         lo, hi = acc.front_range(sums["max_pos"])
                         n_front = h.observe_scalars(ensemble=e, x_wall=acc.x_wall, range_lo=lo, range_hi=hi)["n_range"]
                     acc.add(k, sums, n_front)
+        for ps in systems:
+            ps.steps_done = done
+    finally:
+        h.close()
+    return [acc.result() for acc in accs]
+
+
+def run_batched_structure(systems, T=10.0, obs_dt=0.01, start_fraction=0.5, k_max=None):
+    """The structure observables of PARTICLE_solver_BIOLOGY_local_structure.py:55-103 (time mean / spread of var(total) and of
+    |fft(total)|, dominant mode, low-k power, variance of the local magnetisation, low-k variance) for several systems stepped
+    together as ensembles of one handle, accumulated from per-observation sums taken on the GPU (aps_observe_structure):
+    the reference materialises three M x L arrays per run for them.  `k_max=None` means all L modes, as in the reference.
+    Returns a list of dicts with the reference's eight keys (observables.DeviceStructure.result)."""
+    from . import observables
+    first = systems[0]
+    for ps in systems[1:]:
+        for k in _SHAPE_ATTRS:
+            if getattr(ps, k) != getattr(first, k):
+                raise ValueError(f"run_batched_structure: systems differ in {k}")
+    inits = [ps.init_particles() for ps in systems]
+    seed = first.seed if first.seed is not None else int(first.rng.random() * 2.0 ** 53)
+    if first.dt is None:
+        first.dt = min(ps.default_dt() for ps in systems)
+    for ps in systems:
+        ps.dt, ps.seed_used = first.dt, seed
+    dt = first.dt
+    cap = max(1, max(len(p) for p, _ in inits))
+    h = first._make_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
+    times_obs = np.arange(0.0, T, obs_dt)
+    kk = first.L if k_max is None else min(int(k_max), first.L)
+    accs = [observables.DeviceStructure(len(times_obs), first.L, first.dx, start_fraction, kk) for _ in systems]
+    try:
+        for e, (pos0, sigma0) in enumerate(inits):
+            h.set_state(pos0, sigma0, ensemble=e)
+        done = 0
+        for k, t_obs in enumerate(times_obs):
+            want = int(math.ceil(t_obs / dt - 1e-9))
+            if want > done:
+                h.step(want - done)
+                done = want
+            if k >= accs[0].start:
+                for e, acc in enumerate(accs):
+                    acc.add(k, *h.observe_structure(ensemble=e, k_max=kk))
         for ps in systems:
             ps.steps_done = done
     finally:

@@ -147,6 +147,14 @@ int aps_observe_scalars(aps_handle *h, int32_t ensemble, int32_t x_wall, int32_t
 int aps_observe_scalars_all(aps_handle *h, int32_t x_wall, const int32_t *range_lo_hi, const uint8_t *block_table,
                             int64_t *out11);
 
+/* Structure observables on the device (the inputs of extract_structure_observables_from_out,
+ * PARTICLE_solver_BIOLOGY_local_structure.py:55-103, taken from the current state of one ensemble instead of from the M x L
+ * arrays of run(): ref :527-535): out[0] = live particles n, out[1] = sum over sites of (particles on the site)^2,
+ * out[2], out[3] = sum and sum of squares over the L sites of the local magnetisation m(x) (ref :216-246),
+ * out[4 + 2k], out[5 + 2k] = real and imaginary part of sum_x count(x) exp(-2 pi i k x / L), k = 0 .. k_max - 1
+ * (np.fft.fft(total)[k] times n dx).  out holds 4 + 2 k_max doubles; 1 <= k_max <= L. */
+int aps_observe_structure(aps_handle *h, int32_t ensemble, int32_t k_max, double *out);
+
 /* m-field for a caller-supplied histogram: compute_local_m_field(counts_p, counts_m) (ref :216-246) */
 int aps_field_from_counts(aps_handle *h, int32_t ensemble, const int64_t *counts_p, const int64_t *counts_m,
                           double *m_field);

@@ -15,6 +15,8 @@ Fixture families:
   g5  seeded initial conditions      _init_fixed / _init_poisson            PARTICLE_solver_CLASS.py:141-189
   g4  ensemble statistics            run + sweep-driver observables         ..._sweep_beta.py:123-229, :316-319, :500-525
   g6  hydrodynamic PDE               IMEXPDE.solve                          IMEX_PDE_solver_class.py:236-290
+  g9  custom flip_rate_fn runs       ParticleSystem.run with a callable     PARTICLE_solver_CLASS.py:59-62, :261-262
+  g10 structure observables          extract_structure_observables_from_out PARTICLE_solver_BIOLOGY_local_structure.py:55-103
 """
 import ast
 import json
@@ -462,6 +464,78 @@ def make_g6():
         finally:
             os.chdir(cwd)
     _save("g6_pde.npz", dict(cases=cases, kw=G6_KW, init=dict(rho0=1.0, noise=0.2, n_tracers=300)), arrays)
+
+
+# --------------------------------------------------------------------------------------- g9
+FLIP_FNS = {   # custom flip_rate_fn callables (ref :21, :59-62, applied at :261-262), by name so that tests can rebuild them
+    "glauber": lambda p: (lambda sigma, m: 0.5 * p["nu"] * (1.0 - sigma * np.tanh(p["b"] * m))),
+    "threshold": lambda p: (lambda sigma, m: np.where(sigma * m > p["m0"], p["lo"], p["hi"]).astype(float)),
+}
+
+
+def make_g9():
+    """Seeded trajectories of the reference with a CUSTOM flip_rate_fn (ParticleSystem.run, ref :450-558 with :261-262)."""
+    arrays, cases = {}, []
+    specs = [
+        dict(tag="glauber_k1_reflect", seed=91, fn="glauber", fn_par=dict(nu=2.0, b=1.4),
+             ctor=dict(L=90, N=45, site_capacity=1, init="fixed", local_kernel_sigma=0.03, periodic=False, rate_diffusion=0.4,
+                       rate_active=2.5, beta=0.0, xlim=1.0, scale_rates=False), run=dict(T=1.5, obs_dt=0.25, record_fft=False, record_var=False)),
+        dict(tag="threshold_k2_periodic_anchors", seed=92, fn="threshold", fn_par=dict(m0=0.1, lo=0.2, hi=1.7),
+             ctor=dict(L=80, N=70, site_capacity=2, init="fixed", local_kernel_sigma=0.04, periodic=True, rate_diffusion=0.3,
+                       rate_active=2.0, beta=1.0, xlim=1.0, scale_rates=False, anchor_positions=[0.4], anchor_radius=0.06,
+                       k_on=2.0, k_off=1.0, k_exit=1.5), run=dict(T=1.2, obs_dt=0.2, record_fft=False, record_var=False)),
+    ]
+    for c_idx, sp in enumerate(specs):
+        fn = FLIP_FNS[sp["fn"]](sp["fn_par"])
+        ps = ref_particle.ParticleSystem(rng=np.random.default_rng(sp["seed"]), flip_rate_fn=fn, **sp["ctor"])
+        out = ps.run(**sp["run"])
+        _pack_out(f"c{c_idx}_", out, arrays)
+        cases.append(dict(tag=sp["tag"], seed=sp["seed"], ctor=sp["ctor"], run=sp["run"], fn=sp["fn"], fn_par=sp["fn_par"]))
+        print("  g9", sp["tag"], "final N", out["particle_count_list"][-1], "exits", len(out["exit_times"]))
+    _save("g9_flip_rate_fn.npz", dict(cases=cases), arrays)
+
+
+# --------------------------------------------------------------------------------------- g10
+def _load_structure_observables():
+    """extract_structure_observables_from_out of PARTICLE_solver_BIOLOGY_local_structure.py:55-103, pulled out of the
+    file's syntax tree (the module imports plotting code at its top) and compiled in memory."""
+    path = os.path.join(REF, "PARTICLE_solver_BIOLOGY_local_structure.py")
+    with open(path) as fh:
+        tree = ast.parse(fh.read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "extract_structure_observables_from_out"]
+    assert len(keep) == 1
+    ns = {"np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns["extract_structure_observables_from_out"]
+
+
+def make_g10():
+    """Inputs (var_list, fft_amp_list, m_local_list of small reference runs with record_fft/record_var) and outputs of
+    the reference's structure observables -- pins observables.extract_structure_observables_from_out."""
+    fn = _load_structure_observables()
+    arrays, cases = {}, []
+    specs = [
+        dict(tag="k1_dense", seed=101, k_max=None, start_fraction=0.5,
+             ctor=dict(L=100, xlim=1.0, rate_diffusion=0.1, rate_active=2.0, beta=1.8, init="fixed", N=90, scale_rates=False,
+                       local_kernel_sigma=0.03, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0), run=dict(T=4.0, obs_dt=0.1)),
+        dict(tag="k2_kmax12", seed=102, k_max=12, start_fraction=0.4,
+             ctor=dict(L=128, xlim=1.0, rate_diffusion=0.3, rate_active=1.0, beta=2.5, init="fixed", N=140, scale_rates=False,
+                       local_kernel_sigma=0.05, site_capacity=2, k_on=0.0, k_off=0.0, k_exit=0.0), run=dict(T=3.0, obs_dt=0.125)),
+    ]
+    for c_idx, sp in enumerate(specs):
+        ps = ref_particle.ParticleSystem(rng=np.random.default_rng(sp["seed"]), **sp["ctor"])
+        out = ps.run(record_fft=True, record_var=True, **sp["run"])
+        res = fn(out, start_fraction=sp["start_fraction"], k_max=sp["k_max"])
+        pre = f"c{c_idx}_"
+        for k in ("times_obs", "var_list", "fft_amp_list", "m_local_list", "total_list"):
+            arrays[pre + k] = np.asarray(out[k])
+        arrays[pre + "fft_mean"] = res["fft_mean"]
+        arrays[pre + "fft_std"] = res["fft_std"]
+        cases.append(dict(tag=sp["tag"], k_max=sp["k_max"], start_fraction=sp["start_fraction"], L=sp["ctor"]["L"],
+                          **{k: float(res[k]) for k in ("var_mean", "var_std", "low_k_power", "m_local_var", "lowk_variance")},
+                          dominant_k=int(res["dominant_k"])))
+        print("  g10", sp["tag"], {k: cases[-1][k] for k in ("var_mean", "dominant_k", "low_k_power", "m_local_var")})
+    _save("g10_structure.npz", dict(cases=cases), arrays)
 
 
 # --------------------------------------------------------------------------------------- g8

@@ -47,8 +47,9 @@ def test_drop_in_module_and_loud_failure_without_gpu(capi):
     assert ps.L == 100 and ps.dx == 0.01
     pos, sigma = ps.init_particles()
     assert pos.dtype == np.int64 and sigma.dtype == np.int8 and len(np.unique(pos)) == 10
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match="gillespie"):      # a callable needs the host event loop
         ParticleSystem(L=10, xlim=1, rate_diffusion=0, rate_active=1, beta=1, flip_rate_fn=lambda s, m: s)
+    assert ParticleSystem(L=10, xlim=1, rate_diffusion=0, rate_active=1, beta=1, flip_rate_fn=lambda s, m: s, mode="gillespie").flip_rate_fn
     if capi.device_count() == 0:
         with pytest.raises(capi.ApsError):
             ps.run(T=0.1, obs_dt=0.05)

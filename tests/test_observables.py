@@ -77,3 +77,36 @@ def test_device_observables_formulas_match_reference_functions(golden):
         np.testing.assert_allclose(row["rho"], c["rho"], rtol=1e-9)
         np.testing.assert_allclose(row["block"], c["blk"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(row["D"], c["D"], rtol=1e-7, atol=1e-16)
+
+
+def test_structure_observables_match_reference_function(golden):
+    """observables.structure_observables against the reference's extract_structure_observables_from_out (fixture G10), and
+    the device-side accumulator's host arithmetic (DeviceStructure) fed with sums computed by NumPy from the same frames."""
+    obs = importlib.import_module(PKG + ".observables")
+    g = golden("g10_structure.npz")
+    for idx, c in enumerate(g.meta["cases"]):
+        pre = f"c{idx}_"
+        out = {k: g[pre + k] for k in ("times_obs", "var_list", "fft_amp_list", "m_local_list")}
+        res = obs.structure_observables(out, start_fraction=c["start_fraction"], k_max=c["k_max"])
+        for k in ("var_mean", "var_std", "low_k_power", "m_local_var", "lowk_variance"):
+            np.testing.assert_allclose(res[k], c[k], rtol=1e-13, atol=1e-14, err_msg=(c["tag"], k))   # (a constant series has std ~1e-17)
+        assert res["dominant_k"] == c["dominant_k"]
+        np.testing.assert_allclose(res["fft_mean"], g[pre + "fft_mean"], rtol=1e-13)
+        np.testing.assert_allclose(res["fft_std"], g[pre + "fft_std"], rtol=1e-12)
+        # the device path's arithmetic: integer / float sums per frame instead of the M x L arrays
+        total, L = g[pre + "total_list"], c["L"]
+        dx = 1.0 / L
+        M = len(out["times_obs"])
+        kk = L if c["k_max"] is None else c["k_max"]
+        acc = obs.DeviceStructure(M, L, dx, start_fraction=c["start_fraction"], k_max=c["k_max"])
+        for k in range(M):
+            counts = np.rint(total[k] * dx * np.rint(1.0 / (dx * total[k][total[k] > 0].min()))).astype(np.int64)
+            n = int(counts.sum())
+            ph = np.exp(-2j * np.pi * np.outer(np.arange(kk), np.arange(L)) / L) @ counts
+            m = g[pre + "m_local_list"][k]
+            acc.add(k, n, float((counts ** 2).sum()), float(m.sum()), float((m * m).sum()), np.column_stack([ph.real, ph.imag]))
+        dev = acc.result()
+        for k in ("var_mean", "var_std", "low_k_power", "m_local_var", "lowk_variance"):
+            np.testing.assert_allclose(dev[k], c[k], rtol=1e-9, atol=1e-12, err_msg=(c["tag"], k, "device arithmetic"))
+        assert dev["dominant_k"] == c["dominant_k"]
+        np.testing.assert_allclose(dev["fft_mean"], g[pre + "fft_mean"], rtol=1e-9, atol=1e-9)

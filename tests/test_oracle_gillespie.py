@@ -135,3 +135,23 @@ def test_g3_seeded_trajectories_bit_exact(golden):
                 assert out[k] is None
         assert np.array_equal(np.array(out["exit_times"], dtype=float), g[pre + "exit_times"])
         assert np.array_equal(np.array(out["exit_positions"], dtype=np.int64), g[pre + "exit_positions"])
+
+
+FLIP_FNS = {   # the named callables of fixture G9 (tests/golden/make_fixtures.py)
+    "glauber": lambda p: (lambda sigma, m: 0.5 * p["nu"] * (1.0 - sigma * np.tanh(p["b"] * m))),
+    "threshold": lambda p: (lambda sigma, m: np.where(sigma * m > p["m0"], p["lo"], p["hi"]).astype(float)),
+}
+
+
+def test_g9_custom_flip_rate_fn_trajectories_bit_exact(golden):
+    """A caller-supplied flip_rate_fn (ref :59-62, :261-262): the oracle's event loop reproduces the reference's seeded runs."""
+    g = golden("g9_flip_rate_fn.npz")
+    for idx, c in enumerate(g.meta["cases"]):
+        orc = GillespieOracle(rng=np.random.default_rng(c["seed"]), flip_rate_fn=FLIP_FNS[c["fn"]](c["fn_par"]), **c["ctor"])
+        out = orc.run(**c["run"])
+        pre = f"c{idx}_"
+        assert np.array_equal(np.concatenate(out["pos_list"]), g[pre + "pos_cat"]), c["tag"]
+        assert np.array_equal(np.concatenate(out["bound_list"]), g[pre + "bound_cat"])
+        for k in ("rho_p_list", "rho_m_list", "total_list", "m_global"):
+            assert np.array_equal(out[k], g[pre + k]), (c["tag"], k)
+        assert np.array_equal(np.array(out["exit_times"], dtype=float), g[pre + "exit_times"])
