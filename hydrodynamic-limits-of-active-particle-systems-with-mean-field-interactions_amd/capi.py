@@ -115,6 +115,10 @@ def load():
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
         "aps_comm_ranks": (C.c_int, [vp, P(i32)]),
+        "aps_owned_sites": (C.c_int, [vp, P(i32), P(i32)]),
+        "aps_halo_copy": (C.c_int, [vp, vp]),
+        "aps_halo_pack": (C.c_int, [vp, i32, vp, i64, P(i64)]),
+        "aps_halo_unpack": (C.c_int, [vp, i32, vp, i64]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -234,6 +238,29 @@ class Handle:
     def comm_init(self, id128: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(id128)
         self._ck(self.lib.aps_comm_init(self._h, C.cast(buf, C.c_void_p)))
+
+    def owned_sites(self):
+        """[lo, hi) of the sites this handle steps (the whole lattice unless it is a site-sharded tiles handle)."""
+        lo, hi = C.c_int32(), C.c_int32()
+        self._ck(self.lib.aps_owned_sites(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def halo_from(self, neighbour):
+        """Copy the halo this handle needs from a neighbour rank's handle on the same device (between propose and commit)."""
+        self._ck(self.lib.aps_halo_copy(self._h, neighbour._h))
+
+    def halo_pack(self, side):
+        """This rank's first (side 0) / last (side 1) halo block as a uint8 array (between propose and commit)."""
+        n = C.c_int64()
+        self._ck(self.lib.aps_halo_pack(self._h, int(side), None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), np.uint8)
+        self._ck(self.lib.aps_halo_pack(self._h, int(side), _ptr(buf), len(buf), C.byref(n)))
+        return buf[:n.value]
+
+    def halo_unpack(self, from_side, data):
+        """Store a neighbour's block: from_side 0 = the RIGHT neighbour's first block, 1 = the LEFT neighbour's last block."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        self._ck(self.lib.aps_halo_unpack(self._h, int(from_side), _ptr(data), len(data)))
 
     def comm_ranks(self):
         n = C.c_int32()

@@ -44,6 +44,7 @@ constexpr uint32_t POS_MASK = 0x07FFFFFFu;
 constexpr uint32_t SPIN_BIT = 1u << 27;
 constexpr uint32_t BOUND_BIT = 1u << 28;
 constexpr uint32_t DEAD_BIT = 1u << 29;
+constexpr uint32_t AWAY_BIT = 1u << 30;       // site-sharded handles: the particle currently lives on another rank's sites
 constexpr uint32_t DEAD_P8 = POS_MASK << 3;   // far-away site (x8) every distance test rejects
 constexpr int TILE = 64;                      // slots per tile = one wavefront of targets
 #ifndef APS_WAVES
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(256) void count_sites(const uint32_t *__restrict__ 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Npad) return;
     const uint32_t w = src[(size_t)blockIdx.y * Npad + i];
-    if (w & DEAD_BIT) return;
+    if (w & (DEAD_BIT | AWAY_BIT)) return;
     atomicAdd(&cnt_pm[(size_t)blockIdx.y * L + (w & POS_MASK)], (w & SPIN_BIT) ? 1u : 65536u);
 }
 
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
     long long *out = a.out + (size_t)en * 16;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.Npad; i += gridDim.x * blockDim.x) {
         const uint32_t w = src[i];
-        if (w & DEAD_BIT) continue;
+        if (w & (DEAD_BIT | AWAY_BIT)) continue;
         const int p = (int)(w & POS_MASK);
         const bool plus = (w & SPIN_BIT) != 0;
         v[SC_N] += 1; v[SC_SPIN] += plus ? 1 : -1; v[SC_POS] += p;
@@ -1191,9 +1192,9 @@ __global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uin
 // ---- site-centric state <-> particle-indexed arrays (observation, hooks, upload of the tiles method)
 // cells -> src (live particles only: an exit wrote its own record), occupancy per site
 __global__ __launch_bounds__(256) void cells_to_slots(const uint32_t *__restrict__ cell, const uint32_t *__restrict__ slot_of,
-                                                      uint32_t *src, uint32_t *occ_site, int L, int K, long long N, int Npad) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
-    if (s >= L) return;
+                                                      uint32_t *src, uint32_t *occ_site, int L, int K, long long N, int Npad, int s_lo, int s_hi) {
+    const int s = s_lo + blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (s >= s_hi) return;
     int n = 0;
     for (int k = 0; k < K; ++k) {
         const uint32_t c = cell[((size_t)e * L + s) * K + k];
@@ -1205,12 +1206,18 @@ __global__ __launch_bounds__(256) void cells_to_slots(const uint32_t *__restrict
     occ_site[(size_t)e * L + s] = (uint32_t)n;
 }
 
+// site-sharded handles: before the cells of the own sites are written back, every live record is marked "away"
+__global__ __launch_bounds__(256) void mark_away(uint32_t *src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(src[i] & DEAD_BIT)) src[i] |= AWAY_BIT;
+}
+
 // src -> pre-decoded source words and per-tile info (what apply() maintains in the particle-indexed formulations)
 __global__ __launch_bounds__(256) void derive_slots(const uint32_t *__restrict__ src, uint32_t *sp8, int4 *tinfo, int Npad, int ntiles) {
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     const uint32_t me = src[(size_t)e * Npad + slot];
-    const bool live = !(me & DEAD_BIT);
+    const bool live = !(me & (DEAD_BIT | AWAY_BIT));
     const int p = (int)(me & POS_MASK);
     sp8[(size_t)e * Npad + slot] = live ? (((uint32_t)p << 3) | ((me & SPIN_BIT) ? 1u : 0u)) : DEAD_P8;
     int lo = live ? p : 0x7fffffff, hi = live ? p : -1, cnt = live ? 1 : 0;
@@ -1267,7 +1274,7 @@ __global__ __launch_bounds__(256) void structure_dft(const uint32_t *__restrict_
     double re = 0.0, im = 0.0, n = 0.0;
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
         const uint32_t w = src[i];
-        if (w & DEAD_BIT) continue;
+        if (w & (DEAD_BIT | AWAY_BIT)) continue;
         const long long r = ((long long)k * (long long)(w & POS_MASK)) % (long long)L;   // exact argument reduction
         double sn, cs;
         sincospi(-2.0 * ((double)r / (double)L), &sn, &cs);
@@ -1341,6 +1348,8 @@ struct aps_handle {
     long long *d_gpart[2] = {nullptr, nullptr};
     uint32_t *d_slot_of = nullptr;
     Model *d_model = nullptr; TileRare *d_rare = nullptr;      // device copies read by the tile kernel
+    // site-range sharding of the tiles formulation: this rank steps tiles [ts_lo, ts_hi) = sites [own_lo, own_hi)
+    int ts_lo = 0, ts_hi = 0, own_lo = 0, own_hi = 0, ts_reach = 0;
     int ts_RS = 2, ts_own = 124, ts_ntile = 0, ts_dcap = 0;
     bool ts_table_in_lds = true;
     bool slots_dirty = false;                  // the particle-indexed arrays lag behind the cells
@@ -1741,13 +1750,19 @@ void ts_choose_geometry(aps_handle *h) {
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
     h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K).total <= 160 * 1024;
+    // site-range sharding: contiguous, balanced tile ranges; `reach` = tiles beyond a tile whose deposits can reach its frame
+    h->ts_lo = (int)((int64_t)h->rank * h->ts_ntile / h->world);
+    h->ts_hi = (int)((int64_t)(h->rank + 1) * h->ts_ntile / h->world);
+    h->own_lo = h->ts_lo * h->ts_own;
+    h->own_hi = std::min(L, h->ts_hi * h->ts_own);
+    h->ts_reach = h->model.field_mode ? (h->tlen + 2 + h->ts_own - 1) / h->ts_own : 0;
 }
 
 TileArgs tile_args(aps_handle *h, bool field_only) {
     TileArgs a{};
     const int par = (int)(h->step & 1), out = field_only ? par : par ^ 1;
     a.L = h->p.L; a.K = h->p.K; a.tlen = h->tlen; a.own = h->ts_own; a.ntile = h->ts_ntile; a.dcap = h->ts_dcap; a.par = par;
-    a.tile_lo = 0; a.field_only = field_only ? 1 : 0; a.field_mode = h->model.field_mode; a.ens_base = h->model.ens_base; a.E = h->E;
+    a.tile_lo = h->ts_lo; a.field_only = field_only ? 1 : 0; a.field_mode = h->model.field_mode; a.ens_base = h->model.ens_base; a.E = h->E;
     a.seed_lo = h->model.seed_lo; a.seed_hi = h->model.seed_hi;
     a.model = h->d_model; a.rare = h->d_rare;
     a.ws_in = h->d_wsb[par]; a.ws_out = h->d_wsb[out];
@@ -1762,15 +1777,97 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
     int rc = field_only ? APS_OK : prof_mark(h, KIND_TILE_STEP);
     if (rc) return rc;
     TileArgs a = tile_args(h, field_only);
+    int t0 = h->ts_lo, t1 = h->ts_hi;
+    if (field_only && h->world > 1) {        // also the neighbours' boundary tiles: they hold the two halo sites this rank's frames read
+        t0 = h->p.periodic ? t0 - 1 : std::max(0, t0 - 1);
+        t1 = h->p.periodic ? t1 + 1 : std::min(h->ts_ntile, t1 + 1);
+    }
     const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1);
     const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K).total;
-    const dim3 grid((unsigned)h->ts_ntile, (unsigned)h->E), block(FU_THREADS);
     void *args[] = {(void *)&a, (void *)&h->d_table};
-    if (!field_only && h->profiling && h->prof_dispatch)
-        HIP_TRY(h, hipExtLaunchKernel(fn, grid, block, args, lds, h->stream, h->k_start, h->k_stop, 0));
-    else
-        HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, lds, h->stream));
+    // a range that wraps around the torus (flush of a sharded periodic handle) is launched in pieces
+    struct Piece { int lo, hi; } pieces[3];
+    int np = 0;
+    if (t0 < 0) pieces[np++] = {t0 + h->ts_ntile, h->ts_ntile};
+    pieces[np++] = {std::max(t0, 0), std::min(t1, h->ts_ntile)};
+    if (t1 > h->ts_ntile) pieces[np++] = {0, t1 - h->ts_ntile};
+    for (int i = 0; i < np; ++i) {
+        if (pieces[i].hi <= pieces[i].lo) continue;
+        a.tile_lo = pieces[i].lo;
+        const dim3 grid((unsigned)(pieces[i].hi - pieces[i].lo), (unsigned)h->E), block(FU_THREADS);
+        if (!field_only && h->profiling && h->prof_dispatch)
+            HIP_TRY(h, hipExtLaunchKernel(fn, grid, block, args, lds, h->stream, h->k_start, h->k_stop, 0));
+        else
+            HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, lds, h->stream));
+    }
     if (!field_only) { h->slots_dirty = true; h->field_pending = true; }
+    return APS_OK;
+}
+
+// ---- halo of a site-sharded tiles handle: what the two neighbour ranks need of this rank's freshly written buffers.
+// Everything is addressed by GLOBAL index (every rank allocates the whole lattice), so a segment is received at the very
+// offsets it was sent from.  side 0: this rank's FIRST sites / tiles (for the left neighbour), side 1: its LAST ones.
+struct HaloSeg { size_t off, bytes; int array; };   // array: 0 cells, 1 ws, 2 dcnt, 3 dep (byte offsets into the [buf] arrays)
+
+void halo_segments(const aps_handle *h, int owner_lo_tile, int owner_hi_tile, int side, std::vector<HaloSeg> &out) {
+    const int L = h->p.L, K = h->p.K, own = h->ts_own;
+    const int s_lo = owner_lo_tile * own, s_hi = std::min(L, owner_hi_tile * own);
+    const int nt = std::min(h->ts_reach, owner_hi_tile - owner_lo_tile);
+    for (int e = 0; e < h->E; ++e) {
+        const int c0 = side == 0 ? s_lo : std::max(s_lo, s_hi - 3), c1 = side == 0 ? std::min(s_hi, s_lo + 3) : s_hi;
+        const int w0 = side == 0 ? s_lo : std::max(s_lo, s_hi - 2), w1 = side == 0 ? std::min(s_hi, s_lo + 2) : s_hi;
+        const int t0 = side == 0 ? owner_lo_tile : owner_hi_tile - nt, t1 = t0 + nt;
+        out.push_back({((size_t)e * L + c0) * K * 4, (size_t)(c1 - c0) * K * 4, 0});
+        if (h->model.field_mode) {
+            out.push_back({((size_t)e * L + w0) * sizeof(double2), (size_t)(w1 - w0) * sizeof(double2), 1});
+            out.push_back({((size_t)e * h->ts_ntile + t0) * 4, (size_t)(t1 - t0) * 4, 2});
+            out.push_back({((size_t)e * h->ts_ntile + t0) * h->ts_dcap * 4, (size_t)(t1 - t0) * h->ts_dcap * 4, 3});
+        }
+    }
+}
+
+char *halo_array(aps_handle *h, int array, int buf) {
+    switch (array) {
+        case 0: return reinterpret_cast<char *>(h->d_cell[buf]);
+        case 1: return reinterpret_cast<char *>(h->d_wsb[buf]);
+        case 2: return reinterpret_cast<char *>(h->d_tdcnt[buf]);
+        default: return reinterpret_cast<char *>(h->d_tdep[buf]);
+    }
+}
+
+void rank_tiles(const aps_handle *h, int r, int &lo, int &hi) {
+    lo = (int)((int64_t)r * h->ts_ntile / h->world);
+    hi = (int)((int64_t)(r + 1) * h->ts_ntile / h->world);
+}
+
+// the neighbours of this rank (-1: none, a reflecting wall)
+void halo_peers(const aps_handle *h, int &left, int &right) {
+    left = h->rank - 1; right = h->rank + 1;
+    if (h->p.periodic) { left = (left + h->world) % h->world; right %= h->world; }
+    else { if (right >= h->world) right = -1; }
+}
+
+// after the tile kernel of a step: send this rank's boundary data of the freshly written buffers, receive the neighbours'
+int halo_exchange_rccl(aps_handle *h) {
+    const int buf = (int)((h->step & 1) ^ 1);
+    int left, right;
+    halo_peers(h, left, right);
+    std::vector<HaloSeg> sf, sl, rr, rl;
+    int lo, hi;
+    halo_segments(h, h->ts_lo, h->ts_hi, 0, sf);                       // my first block -> left neighbour
+    halo_segments(h, h->ts_lo, h->ts_hi, 1, sl);                       // my last block  -> right neighbour
+    if (right >= 0) { rank_tiles(h, right, lo, hi); halo_segments(h, lo, hi, 0, rr); }   // the right neighbour's first block
+    if (left >= 0) { rank_tiles(h, left, lo, hi); halo_segments(h, lo, hi, 1, rl); }     // the left neighbour's last block
+    ncclResult_t nr = g_rccl.GroupStart();
+    // order per pair of ranks (matters when left and right are the same rank): sends first-block then last-block,
+    // receives the peer's first-block (it is my right neighbour's) then its last-block
+    if (nr == ncclSuccess && left >= 0) for (const HaloSeg &g : sf) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Send(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, left, h->comm, h->stream);
+    if (nr == ncclSuccess && right >= 0) for (const HaloSeg &g : sl) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Send(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, right, h->comm, h->stream);
+    if (nr == ncclSuccess && right >= 0) for (const HaloSeg &g : rr) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Recv(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, right, h->comm, h->stream);
+    if (nr == ncclSuccess && left >= 0) for (const HaloSeg &g : rl) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Recv(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, left, h->comm, h->stream);
+    const ncclResult_t ge = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ge;
+    if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("halo exchange (ncclSend/ncclRecv): ") + g_rccl.GetErrorString(nr));
     return APS_OK;
 }
 
@@ -1797,8 +1894,12 @@ int sync_slots(aps_handle *h) {
     h->d_ws = h->d_wsb[cur];
     if (!h->slots_dirty) return APS_OK;
     const int L = h->p.L;
-    hipLaunchKernelGGL(cells_to_slots, dim3((unsigned)((L + 255) / 256), (unsigned)h->E), dim3(256), 0, h->stream,
-                       h->d_cell[cur], h->d_slot_of, h->d_src, h->d_occ_site, L, h->p.K, (long long)h->N, (int)h->Npad);
+    const int s_lo = h->world > 1 ? h->own_lo : 0, s_hi = h->world > 1 ? h->own_hi : L;
+    if (h->world > 1)
+        hipLaunchKernelGGL(mark_away, dim3((unsigned)(((size_t)h->E * h->Npad + 255) / 256)), dim3(256), 0, h->stream, h->d_src, (size_t)h->E * h->Npad);
+    if (s_hi > s_lo)
+        hipLaunchKernelGGL(cells_to_slots, dim3((unsigned)((s_hi - s_lo + 255) / 256), (unsigned)h->E), dim3(256), 0, h->stream,
+                           h->d_cell[cur], h->d_slot_of, h->d_src, h->d_occ_site, L, h->p.K, (long long)h->N, (int)h->Npad, s_lo, s_hi);
     hipLaunchKernelGGL(derive_slots, dim3((unsigned)(h->Npad / 256), (unsigned)h->E), dim3(256), 0, h->stream,
                        h->d_src, h->d_sp8, h->d_tinfo, (int)h->Npad, (int)h->ntiles);
     long long *gs = h->d_gsum + (size_t)cur * 2 * h->E;
@@ -1954,9 +2055,11 @@ int aps_create(const aps_params *p, aps_handle **out) {
         h->dcap = (int)std::min<int64_t>(2LL * p->K * B, std::max<int64_t>(2 * p->n_particles, 2));
         const double dep_bytes = (double)h->E * h->nb * h->dcap * 4.0;
         // tiles: site-centric state, one kernel per step (single GPU handles; ids must fit the 30-bit cell field)
-        const bool tiles_ok = p->world == 1 && p->n_particles < (int64_t)CELL_ID && dep_bytes <= 16e9;
-        if (p->method == APS_METHOD_TILES && !tiles_ok) { delete h; return bad("method tiles needs world = 1 and fewer than 2^30 - 1 particles"); }
-        h->method = p->method == APS_METHOD_AUTO ? (tiles_ok ? APS_METHOD_TILES : (dep_bytes <= 16e9 ? APS_METHOD_LATTICE : APS_METHOD_PAIRS)) : p->method;
+        // tiles: site-centric state, one kernel per step; ids must fit the 30-bit cell field.  Sharded (world > 1): by site
+        // ranges with a halo exchange -- needs the local field (the global mean would be an all-reduce) and one ensemble
+        const bool tiles_ok = p->n_particles < (int64_t)CELL_ID && dep_bytes <= 16e9 && (p->world == 1 || M.field_mode);
+        if (p->method == APS_METHOD_TILES && !tiles_ok) { delete h; return bad("method tiles needs fewer than 2^30 - 1 particles and, sharded, a local field (sigma_grid > 0)"); }
+        h->method = p->method == APS_METHOD_AUTO ? ((tiles_ok && p->world == 1) ? APS_METHOD_TILES : (dep_bytes <= 16e9 ? APS_METHOD_LATTICE : APS_METHOD_PAIRS)) : p->method;
         if (const char *env = std::getenv("APS_METHOD")) {    // test / tuning knob for method = auto
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "pairs")) h->method = APS_METHOD_PAIRS;
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "lattice")) h->method = APS_METHOD_LATTICE;
@@ -2006,6 +2109,11 @@ int aps_create(const aps_params *p, aps_handle **out) {
             (rc = dev_alloc(h, &h->d_dcnt, (size_t)h->E * h->nb)) || (rc = dev_alloc(h, &h->d_dep, (size_t)h->E * h->nb * h->dcap)) ||
             (rc = dev_alloc(h, &h->d_stepw, 2)))
             return die(rc);
+    }
+    if (h->method == APS_METHOD_TILES && h->world > 1 && 2 * h->ts_reach + 1 > h->ts_ntile / h->world) {
+        h->err = "tiles, sharded: the table's reach (" + std::to_string(h->ts_reach) + " tiles) must stay below half a rank's tile range (" +
+                 std::to_string(h->ts_ntile / h->world) + " tiles): fewer ranks or a larger lattice";
+        return die(APS_ERR_ARG);
     }
     if (h->method == APS_METHOD_TILES) {
         const size_t ET = (size_t)h->E * h->ts_ntile;
@@ -2120,7 +2228,7 @@ int aps_get_state(aps_handle *h, int32_t e, int32_t *pos, int8_t *sigma, uint8_t
         if (pos) pos[i] = (int32_t)(w & POS_MASK);
         if (sigma) sigma[i] = (w & SPIN_BIT) ? 1 : -1;
         if (bound) bound[i] = (w & BOUND_BIT) ? 1 : 0;
-        if (alive) alive[i] = (w & DEAD_BIT) ? 0 : 1;
+        if (alive) alive[i] = (w & DEAD_BIT) ? 0 : ((w & AWAY_BIT) ? 2 : 1);
     }
     return APS_OK;
 }
@@ -2220,7 +2328,9 @@ void drop_graphs(aps_handle *h) {
 int one_step(aps_handle *h) {
     int rc;
     if ((rc = do_propose(h))) return rc;
-    if (h->comm) {                                           // one in-place all-gather of 1 byte per particle
+    if (h->comm && is_tiles(h)) {                            // site-range shards: boundary sites and deposit lists to the neighbours
+        if (h->world > 1 && (rc = halo_exchange_rccl(h))) return rc;
+    } else if (h->comm) {                                    // one in-place all-gather of 1 byte per particle
         const size_t block = (size_t)h->E * (size_t)h->SH;
         const ncclResult_t nr = g_rccl.AllGather(h->d_prop + block * (size_t)h->rank, h->d_prop, block, ncclUint8, h->comm, h->stream);
         if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
@@ -2577,6 +2687,81 @@ int aps_comm_ranks(aps_handle *h, int32_t *nranks) {
     const ncclResult_t nr = g_rccl.CommCount(h->comm, &n);
     if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("ncclCommCount: ") + g_rccl.GetErrorString(nr));
     *nranks = n;
+    return APS_OK;
+}
+
+int aps_owned_sites(aps_handle *h, int32_t *lo, int32_t *hi) {
+    if (!h) return APS_ERR_ARG;
+    const bool sharded_sites = is_tiles(h) && h->world > 1;
+    if (lo) *lo = sharded_sites ? h->own_lo : 0;
+    if (hi) *hi = sharded_sites ? h->own_hi : h->p.L;
+    return APS_OK;
+}
+
+int aps_halo_copy(aps_handle *dst, aps_handle *src) {
+    if (!dst || !src) return APS_ERR_ARG;
+    aps_handle *h = dst;
+    if (!is_tiles(dst) || !is_tiles(src) || dst->world != src->world || dst->world < 2 || dst->p.L != src->p.L || dst->E != src->E ||
+        dst->ts_own != src->ts_own || dst->ts_dcap != src->ts_dcap || dst->p.K != src->p.K || dst->p.device != src->p.device)
+        return fail(h, APS_ERR_ARG, "aps_halo_copy: both handles must be site-sharded tiles handles of the same shape on one device");
+    int left, right;
+    halo_peers(dst, left, right);
+    if (src->rank != left && src->rank != right) return fail(h, APS_ERR_ARG, "aps_halo_copy: src is not a neighbour rank of dst");
+    HIP_TRY(h, hipStreamSynchronize(src->stream));
+    // both handles have launched this step's kernel and not yet committed: the fresh buffers are [(step & 1) ^ 1] on either side
+    if ((dst->step & 1) != (src->step & 1)) return fail(h, APS_ERR_STATE, "aps_halo_copy: the two handles are at different steps");
+    const int buf = (int)((dst->step & 1) ^ 1);
+    std::vector<HaloSeg> segs;
+    if (src->rank == right) halo_segments(src, src->ts_lo, src->ts_hi, 0, segs);     // the right neighbour's first block
+    if (src->rank == left) halo_segments(src, src->ts_lo, src->ts_hi, 1, segs);      // the left neighbour's last block
+    for (const HaloSeg &g : segs)
+        if (g.bytes) HIP_TRY(h, hipMemcpyAsync(halo_array(dst, g.array, buf) + g.off, halo_array(src, g.array, buf) + g.off, g.bytes, hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(h, hipStreamSynchronize(dst->stream));
+    return APS_OK;
+}
+
+// transport-agnostic halo: this rank's first (side 0) or last (side 1) block as bytes in a host buffer, and the reverse for
+// a block received from a neighbour (from_side 0: the RIGHT neighbour's first block, 1: the LEFT neighbour's last block)
+int aps_halo_pack(aps_handle *h, int32_t side, uint8_t *host, int64_t cap, int64_t *nbytes) {
+    if (!h || !nbytes || side < 0 || side > 1) return APS_ERR_ARG;
+    if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_pack: not a site-sharded tiles handle");
+    std::vector<HaloSeg> segs;
+    halo_segments(h, h->ts_lo, h->ts_hi, side, segs);
+    int64_t total = 0;
+    for (const HaloSeg &g : segs) total += (int64_t)g.bytes;
+    *nbytes = total;
+    if (!host) return APS_OK;
+    if (cap < total) return fail(h, APS_ERR_ARG, "aps_halo_pack: buffer too small");
+    const int buf = (int)((h->step & 1) ^ 1);
+    int64_t off = 0;
+    for (const HaloSeg &g : segs) {
+        if (g.bytes) HIP_TRY(h, hipMemcpyAsync(host + off, halo_array(h, g.array, buf) + g.off, g.bytes, hipMemcpyDeviceToHost, h->stream));
+        off += (int64_t)g.bytes;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+int aps_halo_unpack(aps_handle *h, int32_t from_side, const uint8_t *host, int64_t nbytes) {
+    if (!h || !host || from_side < 0 || from_side > 1) return APS_ERR_ARG;
+    if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_unpack: not a site-sharded tiles handle");
+    int left, right, lo, hi;
+    halo_peers(h, left, right);
+    const int peer = from_side == 0 ? right : left;
+    if (peer < 0) return fail(h, APS_ERR_ARG, "aps_halo_unpack: no neighbour on that side (reflecting wall)");
+    rank_tiles(h, peer, lo, hi);
+    std::vector<HaloSeg> segs;
+    halo_segments(h, lo, hi, from_side, segs);
+    int64_t total = 0;
+    for (const HaloSeg &g : segs) total += (int64_t)g.bytes;
+    if (total != nbytes) return fail(h, APS_ERR_ARG, "aps_halo_unpack: byte count does not match the neighbour's block");
+    const int buf = (int)((h->step & 1) ^ 1);
+    int64_t off = 0;
+    for (const HaloSeg &g : segs) {
+        if (g.bytes) HIP_TRY(h, hipMemcpyAsync(halo_array(h, g.array, buf) + g.off, host + off, g.bytes, hipMemcpyHostToDevice, h->stream));
+        off += (int64_t)g.bytes;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
 }
 

@@ -123,6 +123,21 @@ int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes);
  * propose -> ncclAllGather (in place, 1 byte per particle, on the handle's stream) -> commit per step. */
 int aps_comm_unique_id(uint8_t *out128);
 int aps_comm_init(aps_handle *h, const uint8_t *id128);
+/* APS_METHOD_TILES handles shard by SITE RANGE instead: rank r steps the tiles of sites [lo, hi) (aps_owned_sites) and,
+ * after each step's kernel, exchanges with its two neighbour ranks the three boundary sites of cells, two of {W, S} and the
+ * deposit lists within the table's reach (ncclSend / ncclRecv inside aps_step once aps_comm_init was called).  A caller
+ * that moves the halo itself calls aps_propose (the kernel), transfers, then aps_commit; aps_halo_copy is that transfer
+ * between two handles living on ONE device (tests, single-process multi-handle runs).  On such handles aps_get_state
+ * reports alive = 2 for particles that currently sit on another rank's sites, the lattice arrays are valid on the own sites,
+ * and the scalar observables / exit log cover the own particles: the caller adds them up over the ranks. */
+int aps_owned_sites(aps_handle *h, int32_t *lo, int32_t *hi);
+int aps_halo_copy(aps_handle *dst, aps_handle *src_neighbour);
+/* The same halo through host memory, for any transport: aps_halo_pack copies this rank's first (side 0, for the left
+ * neighbour) or last (side 1, for the right neighbour) block into `host` (host = NULL: only the size), aps_halo_unpack
+ * stores a received block (from_side 0: the RIGHT neighbour's first block, 1: the LEFT neighbour's last block). */
+int aps_halo_pack(aps_handle *h, int32_t side, uint8_t *host, int64_t cap, int64_t *nbytes);
+int aps_halo_unpack(aps_handle *h, int32_t from_side, const uint8_t *host, int64_t nbytes);
+
 /* Number of ranks the communicator of this handle actually spans (ncclCommCount): what a bench line reports as
  * evidence that the exchange ran between that many processes. */
 int aps_comm_ranks(aps_handle *h, int32_t *nranks);

@@ -98,3 +98,96 @@ def test_hip_engine_across_processes(tmp_path, world, method):
         if want_lat is not None:
             for key, w in zip(("W", "S", "occ"), want_lat):
                 assert np.array_equal(got[key], w), (r, key)
+
+
+def _tiles_case():
+    from oracle.gillespie_numpy import LatticeGasParams
+    par = LatticeGasParams.from_kwargs(L=9000, xlim=1.0, rate_diffusion=2.0, rate_active=4.0, beta=1.2, scale_rates=False,
+                                       local_kernel_sigma=0.002, site_capacity=2, anchor_positions=[0.3, 0.6], anchor_radius=0.02,
+                                       k_on=2.0, k_off=1.0, k_exit=0.5)
+    rng = np.random.default_rng(29)
+    n = 8000
+    pos = rng.permutation(rng.choice(np.repeat(np.arange(9000), 2), size=n, replace=False)).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=n)
+    return par, pos, spin
+
+
+def _tiles_worker(rank, world, port, nsteps, out_dir):
+    """One REAL process per rank, each with a site-sharded tiles handle (all on device 0); the halo blocks travel as bytes
+    over gloo (aps_halo_pack / aps_halo_unpack) -- the same blocks ncclSend / ncclRecv move between GPUs in aps_step."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        capi = importlib.import_module(PKG + ".capi")
+        par, pos, spin = _tiles_case()
+        h = _handle(capi, par, len(pos), "tiles", rank, world)
+        h.set_state(pos, spin)
+        left, right = rank - 1, rank + 1                       # reflecting walls: the end ranks have one neighbour
+        for _ in range(nsteps):
+            h.propose()
+            first, last = torch.from_numpy(h.halo_pack(0).copy()), torch.from_numpy(h.halo_pack(1).copy())
+            reqs, from_right, from_left = [], None, None
+            if left >= 0:
+                reqs.append(dist.isend(first, left))
+                from_left = torch.zeros(len(last), dtype=torch.uint8)     # the neighbours' blocks have my blocks' sizes (same shape everywhere)
+                reqs.append(dist.irecv(from_left, left))
+            if right < world:
+                reqs.append(dist.isend(last, right))
+                from_right = torch.zeros(len(first), dtype=torch.uint8)
+                reqs.append(dist.irecv(from_right, right))
+            for q in reqs:
+                q.wait()
+            if from_right is not None:
+                h.halo_unpack(0, from_right.numpy())
+            if from_left is not None:
+                h.halo_unpack(1, from_left.numpy())
+            h.commit()
+        p, s, b, a = h.get_state()
+        lo, hi = h.owned_sites()
+        W, S, occ = h.get_lattice()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=p, spin=s, bound=b, alive=a, exits=h.exits(), lo=lo, hi=hi, W=W, S=S, occ=occ)
+        h.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_site_sharded_tiles_across_processes(tmp_path, world):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    capi = importlib.import_module(PKG + ".capi")
+    nsteps = 50
+    port = 31200 + (os.getpid() % 1500) + 11 * world
+    mp.spawn(_tiles_worker, args=(world, port, nsteps, str(tmp_path)), nprocs=world, join=True)
+    par, pos, spin = _tiles_case()
+    single = _handle(capi, par, len(pos), "tiles")
+    try:
+        single.set_state(pos, spin)
+        single.step(nsteps)
+        want = single.get_state()
+        want_exits = single.exits()
+        Ws, Ss, occs = single.get_lattice()
+    finally:
+        single.close()
+    assert (want[3] == 0).any(), "the case should exercise exits"
+    n = len(pos)
+    seen, exits = np.zeros(n, int), []
+    merged = [np.zeros(n, np.int32), np.zeros(n, np.int8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        mine = got["alive"] != 2
+        seen += mine
+        for m, key in zip(merged, ("pos", "spin", "bound", "alive")):
+            m[mine] = got[key][mine]
+        lo, hi = int(got["lo"]), int(got["hi"])
+        assert np.array_equal(got["W"][lo:hi], Ws[lo:hi]) and np.array_equal(got["S"][lo:hi], Ss[lo:hi]) and np.array_equal(got["occ"][lo:hi], occs[lo:hi])
+        exits.append(got["exits"])
+    assert np.array_equal(seen, np.ones(n, int))                 # every particle owned by exactly one rank
+    for m, w in zip(merged, want):
+        assert np.array_equal(m, w)
+    ex = np.concatenate(exits)
+    assert np.array_equal(ex[np.lexsort((ex[:, 2], ex[:, 0]))], want_exits)

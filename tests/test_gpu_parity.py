@@ -639,3 +639,67 @@ def test_lattice_graph_replay_long_run(capi, case):
         check_lattice(h, orc)
     finally:
         h.close()
+
+
+def _merged_state(handles, n):
+    """Global state from site-sharded handles: every particle is reported (alive != 2) by exactly one rank."""
+    pos, spin, bound, alive = np.zeros(n, np.int32), np.zeros(n, np.int8), np.zeros(n, np.uint8), np.full(n, 255, np.uint8)
+    seen = np.zeros(n, int)
+    for h in handles:
+        p, s, b, a = h.get_state()
+        mine = a != 2
+        pos[mine], spin[mine], bound[mine], alive[mine] = p[mine], s[mine], b[mine], a[mine]
+        seen += mine
+    return pos, spin, bound, alive, seen
+
+
+@pytest.mark.parametrize("world,periodic", [(2, False), (3, False), (2, True), (4, True)])
+def test_site_sharded_tiles_equal_single_handle(capi, world, periodic):
+    """Site-range sharding of the tiles formulation, emulated with `world` handles on ONE device: every rank steps its own
+    tiles (aps_propose), the halo (3 sites of cells, 2 of {W, S}, the deposit lists within reach) is copied from the
+    neighbour handles (aps_halo_copy = what ncclSend / ncclRecv move between GPUs), aps_commit.  The merged state equals
+    the single-handle run and the oracle after every block of steps; every particle is owned by exactly one rank;
+    W, S on the own sites equal the single handle's; exits add up."""
+    par = params(L=6000, K=2, sigma=0.002, periodic=periodic, anchor_positions=[0.25, 0.5, 0.75], anchor_radius=0.02,
+                 k_on=2.0, k_off=1.0, k_exit=0.7, rate_diffusion=3.0)
+    rng = np.random.default_rng(77)
+    N = 5200
+    pos, spin = random_state(rng, par.L, N, par.K)
+    orc = so.SyncOracle(par, dt=0.04, seed=31)
+    orc.set_state(pos, spin)
+    ranks = [make_handle(capi, par, N, dt=0.04, seed=31, rank=r, world=world, method="tiles") for r in range(world)]
+    single = make_handle(capi, par, N, dt=0.04, seed=31, method="tiles")
+    try:
+        bounds = [h.owned_sites() for h in ranks]
+        assert bounds[0][0] == 0 and bounds[-1][1] == par.L and all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))
+        with pytest.raises(capi.ApsError):
+            ranks[0].step(1)                                  # aps_step needs a communicator on sharded handles
+        for h in ranks + [single]:
+            h.set_state(pos, spin)
+        for block in range(6):
+            for _ in range(20):
+                for h in ranks:
+                    h.propose()
+                for r, h in enumerate(ranks):
+                    nb = {(r - 1) % world, (r + 1) % world} if periodic else {q for q in (r - 1, r + 1) if 0 <= q < world}
+                    for q in sorted(nb):
+                        h.halo_from(ranks[q])
+                for h in ranks:
+                    h.commit()
+            single.step(20)
+            orc.run(20)
+            p, s, b, a, seen = _merged_state(ranks, N)
+            assert np.array_equal(seen, np.ones(N, int)), block
+            for x, y in zip((p, s, b, a), single.get_state()):
+                assert np.array_equal(x, y), block
+            assert np.array_equal(p, orc.pos) and np.array_equal(s, orc.spin) and np.array_equal(a, orc.alive)
+        Ws, Ss, occs = single.get_lattice()
+        for h, (lo, hi) in zip(ranks, bounds):
+            W, S, occ = h.get_lattice()
+            assert np.array_equal(W[lo:hi], Ws[lo:hi]) and np.array_equal(S[lo:hi], Ss[lo:hi]) and np.array_equal(occ[lo:hi], occs[lo:hi])
+        ex = np.concatenate([h.exits() for h in ranks])
+        ex = ex[np.lexsort((ex[:, 2], ex[:, 0]))]
+        assert len(ex) > 0 and np.array_equal(ex, single.exits())
+    finally:
+        for h in ranks + [single]:
+            h.close()
