@@ -303,27 +303,70 @@ def main():
     pos, spin = initial_state(w)
     roof, comm_path, extra = None, "", {}
     sharded_path = world > 1 or os.environ.get("APS_BENCH_FORCE_SHARDED") == "1"   # the switch lets one rank rehearse it
-    if sharded_path:
+    scaling, sharding_note, exchange, ranks_seen = "strong", "", "", None
+    if sharded_path and n_ens > 1:
+        # Independent ensembles (BASELINE config 4) across GPUs: every rank steps its own n_ens ensembles (its own beta
+        # values and Philox streams), no data-path communication at all -- the weak / throughput curve.
+        import torch
+        import torch.distributed as dist
+        device = int(os.environ.get("APS_BENCH_DEVICE", local_rank))
+        torch.cuda.set_device(device)
+        with stdout_to_stderr():
+            dist.init_process_group("gloo")                  # barriers and the MAX over ranks only
+        lo, hi = min(w["betas"]), max(w["betas"])
+        all_betas = [lo + (hi - lo) * i / (n_ens * world - 1) for i in range(n_ens * world)]
+        wr = dict(w, betas=all_betas[rank * n_ens:(rank + 1) * n_ens])
+        h = capi.Handle(L=wr["L"], K=wr["K"], periodic=False, sigma_grid=wr["sigma"] / (wr["xlim"] / wr["L"]),
+                        rate_diffusion=wr["rate_diffusion"], rate_active=wr["rate_active"], beta=wr["betas"], dt=wr["dt"],
+                        seed=wr["seed"], n_particles=wr["N"], device=device, ensemble_base=rank * n_ens, method=args.method)
+        for e in range(n_ens):
+            h.set_state(pos, spin, ensemble=e)
+        h.step(args.warmup)
+        times = []
+        for _ in range(max(1, args.repeats)):
+            dist.barrier()
+            t0 = time.perf_counter()
+            h.step(args.steps)
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.barrier()
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            times.append(float(el.item()))
+        elapsed = float(np.median(times))
+        extra = {"repeats": len(times), "repeats_ms_per_step": [t / args.steps * 1e3 for t in times], "graph_replay": h.step_info()[0] > 0}
+        scaling, exchange, ranks_seen = "weak", "none (independent ensembles)", dist.get_world_size()
+        sharding_note = f"{n_ens} ensembles per GPU x {world} GPU(s), no data-path communication"
+        n_ens_total = n_ens * world
+    elif sharded_path:
         import torch
         import torch.distributed as dist
         device = int(os.environ.get("APS_BENCH_DEVICE", local_rank))   # rehearsals put several ranks on one GPU
         torch.cuda.set_device(device)
         with stdout_to_stderr():                             # gloo announces its connections on stdout
             dist.init_process_group("gloo")                  # rendezvous / barriers only; the data path is RCCL below
-        h = make_handle(capi, w, device=device, rank=rank, world=world, method=args.method)
-        h.set_state(pos, spin)
 
         def all_agree(ok):
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1
 
-        # The exchange of the proposal bytes, in order of preference (APS_BENCH_EXCHANGE forces one):
-        #   rccl        the library all-gathers itself (ncclAllGather on its stream, no Python per step)
-        #   torch-nccl  torch.distributed backend "nccl" (= RCCL) on a torch tensor bound to the library
-        #   gloo-host   host copies + gloo: always works (even with several ranks on one GPU); slow, last resort
+        # ONE system over several GPUs (BASELINE config 3).  Preferred: site-range shards of the tiles formulation
+        # (every rank steps its own tiles; halo by ncclSend / ncclRecv); if the table's reach does not fit the ranks'
+        # ranges: particle-index shards (every rank applies all proposals; all-gather of 1 byte per particle).
+        h, site_shards = None, False
+        if args.method in ("auto", "tiles"):
+            try:
+                h = make_handle(capi, w, device=device, rank=rank, world=world, method="tiles")
+                site_shards = True
+            except capi.ApsError as exc:
+                print(f"[rank {rank}] site-range shards unavailable ({exc}); particle-index shards instead", file=sys.stderr)
+        site_shards = all_agree(site_shards)
+        if not site_shards:
+            if h is not None:
+                h.close()
+            h = make_handle(capi, w, device=device, rank=rank, world=world, method="auto" if args.method == "tiles" else args.method)
+        h.set_state(pos, spin)
         forced = os.environ.get("APS_BENCH_EXCHANGE", "")
-        run, path, exchange, ranks_seen = None, "", "", None
+        run, path = None, ""
         if forced in ("", "rccl"):
             ids = [None]
             if rank == 0:                                    # a failure here must not unbalance the collectives below
@@ -338,18 +381,19 @@ def main():
                 try:
                     with stdout_to_stderr():
                         h.comm_init(ids[0])
-                        h.step(1)                            # first collective (lazy channel setup) also under the redirect
+                        h.step(1)                            # first exchange (lazy channel setup) also under the redirect
                 except Exception as exc:                     # noqa: BLE001
                     ok = False
                     print(f"[rank {rank}] in-library RCCL unavailable ({exc})", file=sys.stderr)
             if all_agree(ok):
-                run, path, exchange = h.step, "in-library RCCL all-gather", "rccl"
+                run, exchange = h.step, "rccl"
+                path = "in-library RCCL: " + ("ncclSend/ncclRecv of the halo to the two neighbour ranks" if site_shards else "all-gather of the proposal bytes")
                 ranks_seen = h.comm_ranks()
             elif ok:                                         # this rank has a communicator the others lack: start over without it
                 h.close()
-                h = make_handle(capi, w, device=device, rank=rank, world=world, method=args.method)
+                h = make_handle(capi, w, device=device, rank=rank, world=world, method="tiles" if site_shards else args.method)
                 h.set_state(pos, spin)
-        if run is None and forced in ("", "rccl", "torch-nccl"):
+        if run is None and not site_shards and forced in ("", "rccl", "torch-nccl"):
             sharded = importlib.import_module(PKG + ".sharded")
             ok, stepper = True, None
             try:
@@ -372,23 +416,45 @@ def main():
             # only a rehearsal with several ranks on one GPU may fall back to host copies: with a device per rank the
             # missing RCCL path is an error, not something to time and report as the multi-GPU result
             if capi.device_count() >= world and forced != "gloo-host":
-                raise SystemExit(f"bench.py: rank {rank}: neither in-library RCCL nor torch.distributed nccl works between "
-                                 f"{world} ranks on {capi.device_count()} devices; refusing to time the host-copy fallback")
+                raise SystemExit(f"bench.py: rank {rank}: no RCCL path works between {world} ranks on {capi.device_count()} devices; "
+                                 "refusing to time the host-copy fallback")
             path, exchange = "host copies + torch.distributed gloo (rehearsal: several ranks share one GPU)", "gloo-host"
             ranks_seen = dist.get_world_size()
-            _, total, off, mine = h.exchange_buffer()
-            buf = torch.zeros(total, dtype=torch.uint8, device=torch.device("cuda", device))
-            h.set_stream(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
-            h.bind_exchange_buffer(buf.data_ptr(), total)
-            gathered = [torch.zeros(mine, dtype=torch.uint8) for _ in range(world)]
+            if site_shards:
+                left, right = rank - 1, rank + 1
 
-            def run(n):
-                for _ in range(int(n)):
-                    h.propose()
-                    dist.all_gather(gathered, buf[off:off + mine].cpu())
-                    buf.copy_(torch.cat(gathered))
-                    h.commit()
-                torch.cuda.synchronize()
+                def run(n):
+                    for _ in range(int(n)):
+                        h.propose()
+                        first, last = torch.from_numpy(h.halo_pack(0).copy()), torch.from_numpy(h.halo_pack(1).copy())
+                        reqs, from_left, from_right = [], None, None
+                        if left >= 0:
+                            from_left = torch.zeros(len(last), dtype=torch.uint8)
+                            reqs += [dist.isend(first, left), dist.irecv(from_left, left)]
+                        if right < world:
+                            from_right = torch.zeros(len(first), dtype=torch.uint8)
+                            reqs += [dist.isend(last, right), dist.irecv(from_right, right)]
+                        for q in reqs:
+                            q.wait()
+                        if from_right is not None:
+                            h.halo_unpack(0, from_right.numpy())
+                        if from_left is not None:
+                            h.halo_unpack(1, from_left.numpy())
+                        h.commit()
+            else:
+                _, total, off, mine = h.exchange_buffer()
+                buf = torch.zeros(total, dtype=torch.uint8, device=torch.device("cuda", device))
+                h.set_stream(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
+                h.bind_exchange_buffer(buf.data_ptr(), total)
+                gathered = [torch.zeros(mine, dtype=torch.uint8) for _ in range(world)]
+
+                def run(n):
+                    for _ in range(int(n)):
+                        h.propose()
+                        dist.all_gather(gathered, buf[off:off + mine].cpu())
+                        buf.copy_(torch.cat(gathered))
+                        h.commit()
+                    torch.cuda.synchronize()
         run(args.warmup)
         times = []
         for _ in range(max(1, args.repeats)):                # each repeat: barrier, K steps, drain, barrier; MAX over ranks
@@ -401,14 +467,22 @@ def main():
             times.append(float(el.item()))
         elapsed = float(np.median(times))
         extra = {"repeats": len(times), "repeats_ms_per_step": [t / args.steps * 1e3 for t in times], "graph_replay": False}
-        # every rank must hold the same state; compare a checksum
+        # consistency across ranks: site shards -> every particle is owned by exactly one rank; index shards -> same state everywhere
         p, s, b, a = h.get_state()
-        chk = torch.tensor([int(p.astype(np.int64).sum()), int((s > 0).sum())], dtype=torch.int64)
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert bool((lo == hi).all()), "ranks diverged"
+        if site_shards:
+            owned = torch.tensor([int((a != 2).sum()), int(p[a == 1].astype(np.int64).sum())], dtype=torch.int64)
+            dist.all_reduce(owned, op=dist.ReduceOp.SUM)
+            assert int(owned[0]) == w["N"], f"ranks own {int(owned[0])} particles of {w['N']}"
+        else:
+            chk = torch.tensor([int(p.astype(np.int64).sum()), int((s > 0).sum())], dtype=torch.int64)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert bool((lo == hi).all()), "ranks diverged"
         comm_path = path
+        sharding_note = ("site ranges of one system over %d GPU(s), per step a halo of 3 sites + the deposit lists within reach to each neighbour" % world
+                         if site_shards else "particle index over %d GPU(s), 1 all-gather of 1 B/particle per step" % world) + f" ({path})"
+        n_ens_total = n_ens
     else:
         h = make_handle(capi, w, method=args.method)
         for e in range(n_ens):
@@ -477,22 +551,23 @@ def main():
                                    "frac": step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS},
                     "deposits_per_step": dep_per_step, "kernels_per_step": len(kern)}
         roof = dict(roof or {}, **{"hbm_copy_GBps": hbm_copy})
+    if not sharded_path:
+        n_ens_total, sharding_note = n_ens, "one GPU"
     p, s, b, a = h.get_state()
-    assert a.all() and np.bincount(p, minlength=w["L"]).max() <= w["K"]
+    assert (a != 0).all() and np.bincount(p[a == 1], minlength=w["L"]).max() <= w["K"]
     h_method = h.method
     h.close()
     if rank != 0:
         return
     out = {
-        "metric": "particle-steps/sec at N=1e5", "value": w["N"] * n_ens * args.steps / elapsed, "unit": "particle-steps/s",
+        "metric": "particle-steps/sec at N=1e5", "value": w["N"] * n_ens_total * args.steps / elapsed, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
                                 "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on") if args.workload == "config2"
                                else f"{'BASELINE ' if args.workload.startswith('config') else ''}{args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma_g={w['sigma'] * w['L']:.0f} sites, dt=0.0125",
                    "method": h_method,
-                   "sharding": f"particle index over {world} GPU(s), 1 all-gather of 1 B/particle per step"
-                               + (f" ({comm_path})" if sharded_path else "")},
+                   "sharding": sharding_note},
     }
     if sharded_path:
         out["exchange"], out["ranks_seen"] = exchange, ranks_seen

@@ -12,7 +12,7 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_lattice_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench_config2.json")) as f:
         line = json.load(f)
     for key in CONTRACT:
         assert key in line, key
@@ -23,6 +23,13 @@ def test_committed_bench_line_has_the_contract_fields():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    # round-2 harness: the measured limiter next to the contract's bound, this box's copy-kernel ceiling, per-workload
+    # traffic (a number recorded for this workload or null), median of >= 5 repeats, how the timed steps were launched
+    assert roof["bound_measured"] and 1000.0 < roof["hbm_copy_GBps"] < 8000.0 and roof["kernels_per_step"] <= 2
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    assert line["repeats"] >= 5 and len(line["repeats_ms_per_step"]) == line["repeats"]
+    assert abs(line["ms_per_step"] - sorted(line["repeats_ms_per_step"])[len(line["repeats_ms_per_step"]) // 2]) < 1e-12
+    assert isinstance(line["graph_replay"], bool) and line["steps_from_graphs"] + line["steps_launched_singly"] == line["steps"]
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * roof["achieved"]
     cpu = line["cpu_baseline"]
@@ -41,3 +48,40 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0
     assert r.stdout.strip() == ""                            # no JSON line, nothing measured
     assert "GPU" in r.stderr or "device" in r.stderr.lower()
+
+
+def test_gpus_flag_spawns_one_rank_per_gpu_without_touching_the_gpu_in_the_parent():
+    """`python bench.py --gpus N` (no launcher): the parent starts N rank processes with the torchrun environment and relays
+    rank 0's line; it never imports the C-ABI binding (a process that initialised the GPU must not be re-exec'd, and the
+    parent needs no GPU at all)."""
+    import io
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    before = set(sys.modules)
+    spec.loader.exec_module(bench)
+    made = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            self.cmd, self.env, self.returncode = cmd, env, 0
+            self.stdout = io.StringIO('{"n_gpus": 3}\n') if env["RANK"] == "0" else None
+            made.append(self)
+
+        def poll(self):
+            return 0
+
+        def wait(self, timeout=None):
+            return 0
+
+    rc = bench.spawn_ranks(3, ["--gpus", "3", "--steps", "4"], popen=FakeProc, port=23456)
+    assert rc == 0 and len(made) == 3
+    for r, p in enumerate(made):
+        assert p.env["RANK"] == p.env["LOCAL_RANK"] == str(r) and p.env["WORLD_SIZE"] == "3"
+        assert p.env["MASTER_ADDR"] == "127.0.0.1" and p.env["MASTER_PORT"] == "23456"
+        assert p.cmd[0] == sys.executable and p.cmd[1].endswith("bench.py") and p.cmd[2:] == ["--gpus", "3", "--steps", "4"]
+    assert not any("capi" in m for m in set(sys.modules) - before), "the launcher parent must not load the GPU binding"
+    # a launcher that disagrees with --gpus is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "disagrees" in r.stderr
