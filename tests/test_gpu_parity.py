@@ -353,7 +353,8 @@ def test_config2_ten_thousand_steps_field_stays_exact(capi):
         b.close()
 
 
-def test_config5_scale_incremental_field_equals_from_scratch(capi):
+@pytest.mark.parametrize("method", ["lattice", "tiles"])
+def test_config5_scale_incremental_field_equals_from_scratch(capi, method):
     """BASELINE config 5 scale (N = 1e6, L = 2e6, 40 001-entry table = 320 KB, beyond LDS): the field kept incrementally by
     `field_update` (table windows in LDS for interior tiles, global gathers next to the walls) over 300 steps equals the one
     a fresh handle builds from scratch from the final state with the `field_sites` kernel (itself pinned to the oracle at
@@ -364,8 +365,8 @@ def test_config5_scale_incremental_field_equals_from_scratch(capi):
     rng = np.random.default_rng(11)
     pos = rng.choice(L, size=N, replace=False).astype(np.int32)
     spin = rng.choice(np.array([1, -1], np.int8), size=N)
-    a = make_handle(capi, par, N, dt=0.0125, seed=4, method="lattice")
-    b = make_handle(capi, par, N, dt=0.0125, seed=4, method="lattice")
+    a = make_handle(capi, par, N, dt=0.0125, seed=4, method=method)
+    b = make_handle(capi, par, N, dt=0.0125, seed=4, method=method)
     try:
         assert len(a.table()[0]) == 40001
         a.set_state(pos, spin)
@@ -703,3 +704,93 @@ def test_site_sharded_tiles_equal_single_handle(capi, world, periodic):
     finally:
         for h in ranks + [single]:
             h.close()
+
+
+def _oracle_window_field(table, pos, spin, L, a, b):
+    """W, S on the sites [a, b) by the oracle's lattice formula (histogram -> stencil with the reflected images, the
+    arithmetic of oracle/sync_oracle.c:field_at) restricted to a window.  Every weight sits on the grid 2^-q, so these
+    NumPy sums are exact whatever their order."""
+    Rt = len(table) - 1
+    cp = np.bincount(pos[spin > 0], minlength=L).astype(np.float64)
+    cm = np.bincount(pos[spin < 0], minlength=L).astype(np.float64)
+    tot, sgn = cp + cm, cp - cm
+    lo, hi = a - Rt, b + Rt                                   # source sites that can reach the window; beyond a wall: the images
+    idx = np.arange(lo, hi)
+    refl = np.where(idx < 0, -1 - idx, np.where(idx >= L, 2 * L - 1 - idx, idx))   # site -1 - y mirrors y, 2L - 1 - y mirrors y
+    wsym = np.concatenate([table[::-1], table[1:]])
+    W = np.convolve(tot[refl], wsym, mode="valid")
+    S = np.convolve(sgn[refl], wsym, mode="valid")
+    assert len(W) == b - a
+    return W, S
+
+
+@pytest.mark.parametrize("method", ["lattice", "tiles"])
+def test_config5_scale_field_against_oracle_windows(capi, method):
+    """BASELINE config 5 scale (N = 1e6, L = 2e6, 40 001-entry table beyond LDS) against the ORACLE, where the oracle can go:
+    after 200 steps the incrementally kept W, S are compared bit for bit with the oracle's stencil formula on four windows
+    -- at the left wall (image deposits), where the tiles change from the wall path to the windowed path (x ~ reach), deep
+    in the interior, and at the right wall -- with the oracle's own weight table (equal to the library's)."""
+    L, N = 2_000_000, 1_000_000
+    par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7,
+                                       scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
+    rng = np.random.default_rng(12)
+    pos = rng.choice(L, size=N, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=N)
+    h = make_handle(capi, par, N, dt=0.0125, seed=6, method=method)
+    try:
+        assert h.method == method
+        tab, q = h.table()
+        otab, oq = so.build_table(par.sigma_grid, L, 1, False)
+        assert q == oq and np.array_equal(tab, otab[:len(tab)]) and len(tab) == 40001
+        h.set_state(pos, spin)
+        h.step(200)
+        p, s, _, alive = h.get_state()
+        assert alive.all() and (p != pos).mean() > 0.25 and np.bincount(p, minlength=L).max() <= 1
+        W, S, occ = h.get_lattice(0)
+        assert np.array_equal(occ, np.bincount(p, minlength=L))
+        Rt = len(tab) - 1
+        for a0, b0 in ((0, 700), (Rt - 900, Rt + 900), (L // 2 - 300, L // 2 + 500), (L - Rt - 700, L - Rt + 700), (L - 700, L)):
+            W0, S0 = _oracle_window_field(tab, p.astype(np.int64), s, L, a0, b0)
+            assert np.array_equal(W[a0:b0], W0), (method, a0)
+            assert np.array_equal(S[a0:b0], S0), (method, a0)
+    finally:
+        h.close()
+
+
+def test_config4_full_size_ensembles(capi):
+    """BASELINE config 4 at its full size: 16 beta-ensembles x N = 5e4 on L = 1e5 in ONE handle.  After 150 steps: exclusion
+    and conservation in every ensemble; the first and the last ensemble equal single-ensemble handles with the same
+    Philox stream (ensemble_base) bit for bit; the incrementally kept W, S, occupancy of those two equal the ORACLE's
+    recomputation from their final states; the beta = 0 and beta = 3 ensembles have drifted apart (ordering)."""
+    L, N, E = 100_000, 50_000, 16
+    betas = [3.0 * i / 15 for i in range(E)]
+    par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7,
+                                       scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
+    rng = np.random.default_rng(44)
+    states = [(rng.choice(L, size=N, replace=False).astype(np.int32), rng.choice(np.array([1, -1], np.int8), size=N)) for _ in range(E)]
+    big = make_handle(capi, par, N, dt=0.0125, seed=9, beta=betas)
+    try:
+        assert big.method == "tiles"
+        for e, (p0, s0) in enumerate(states):
+            big.set_state(p0, s0, ensemble=e)
+        big.step(150)
+        finals = [big.get_state(ensemble=e) for e in range(E)]
+        for e, (p, s, b, al) in enumerate(finals):
+            assert al.all() and np.bincount(p, minlength=L).max() <= 1 and np.abs(p.astype(int) - states[e][0]).max() <= 150
+        assert abs(float(finals[15][1].mean())) > abs(float(finals[0][1].mean())) + 0.05     # beta = 3 orders, beta = 0 does not
+        for e in (0, E - 1):
+            one = make_handle(capi, par, N, dt=0.0125, seed=9, beta=[betas[e]], ensemble_base=e)
+            try:
+                one.set_state(*states[e])
+                one.step(150)
+                for x, y in zip(finals[e], one.get_state()):
+                    assert np.array_equal(x, y), e
+            finally:
+                one.close()
+            orc_par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=betas[e],
+                                                   scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
+            orc = so.SyncOracle(orc_par, dt=0.0125, seed=9, ensemble=e)
+            orc.set_state(finals[e][0], finals[e][1])
+            check_lattice(big, orc, ensemble=e)
+    finally:
+        big.close()
