@@ -111,6 +111,7 @@ def load():
         "aps_observe_scalars_all": (C.c_int, [vp, i32, vp, vp, vp]),
         "aps_event_overhead": (C.c_int, [vp, i32, P(dbl)]),
         "aps_observe_structure": (C.c_int, [vp, i32, i32, vp]),
+        "aps_observe_bins": (C.c_int, [vp, i32, i32, vp, vp]),
         "aps_rates_from_field": (C.c_int, [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]),
         "aps_comm_unique_id": (C.c_int, [vp]),
         "aps_comm_init": (C.c_int, [vp, vp]),
@@ -319,6 +320,12 @@ class Handle:
         rng = None if ranges is None else np.ascontiguousarray(ranges, dtype=np.int32).reshape(self.E, 2)
         self._ck(self.lib.aps_observe_scalars_all(self._h, int(x_wall), _ptr(rng), _ptr(tab), _ptr(out)))
         return [{k: int(v) for k, v in zip(self.SCALARS, row)} for row in out]
+
+    def observe_bins(self, nbins, ensemble=0):
+        """(plus, minus) live particles per bin of ceil(L / nbins) consecutive sites, counted on the device."""
+        cp, cm = np.zeros(nbins, np.int64), np.zeros(nbins, np.int64)
+        self._ck(self.lib.aps_observe_bins(self._h, ensemble, int(nbins), _ptr(cp), _ptr(cm)))
+        return cp, cm
 
     def observe_structure(self, ensemble=0, k_max=25):
         """(n live, sum count^2 over sites, sum m, sum m^2 over sites, [k_max][2] Fourier sums of the site histogram)."""

@@ -1290,6 +1290,16 @@ __global__ __launch_bounds__(256) void structure_dft(const uint32_t *__restrict_
     if (threadIdx.x == 0) { out[4 + 2 * k] = acc[0]; out[5 + 2 * k] = acc[1]; if (k == 0) out[0] = acc[2]; }
 }
 
+// coarse-grained site histograms: particles of either spin per bin of `bin_sites` consecutive sites (the PDE grid of the
+// hydrodynamic-limit comparison, BASELINE config 5); exact integers
+__global__ __launch_bounds__(256) void bin_counts(const uint32_t *__restrict__ src, int Npad, int bin_sites, unsigned long long *plus, unsigned long long *minus) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Npad) return;
+    const uint32_t w = src[i];
+    if (w & (DEAD_BIT | AWAY_BIT)) return;
+    atomicAdd(((w & SPIN_BIT) ? plus : minus) + (w & POS_MASK) / (uint32_t)bin_sites, 1ull);
+}
+
 // ---------------------------------------------------------------------------------------------
 std::string g_create_error;
 
@@ -2569,6 +2579,24 @@ int aps_observe_structure(aps_handle *h, int32_t e, int32_t k_max, double *out) 
     hipLaunchKernelGGL(structure_dft, dim3((unsigned)k_max), dim3(256), 0, h->stream, src, (int)h->Npad, L, d_out);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_structure: kernel or copy failed"));
+    return done(APS_OK);
+}
+
+int aps_observe_bins(aps_handle *h, int32_t e, int32_t nbins, int64_t *plus, int64_t *minus) {
+    if (!h) return APS_ERR_ARG;
+    if (e < 0 || e >= h->E || !plus || !minus || nbins < 1 || nbins > h->p.L) return fail(h, APS_ERR_ARG, "aps_observe_bins: bad argument");
+    if (h->n_set[(size_t)e] < 0) return fail(h, APS_ERR_STATE, "aps_observe_bins: no state uploaded for this ensemble");
+    int rc = sync_slots(h);
+    if (rc) return rc;
+    const int bin_sites = (h->p.L + nbins - 1) / nbins;
+    unsigned long long *d = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&d), (size_t)2 * nbins * 8));
+    auto done = [&](int code) { (void)hipFree(d); return code; };
+    if (hipMemsetAsync(d, 0, (size_t)2 * nbins * 8, h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_bins: memset failed"));
+    hipLaunchKernelGGL(bin_counts, dim3((unsigned)(h->Npad / 256)), dim3(256), 0, h->stream, h->d_src + (size_t)e * h->Npad, (int)h->Npad, bin_sites, d, d + nbins);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(plus, d, (size_t)nbins * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(minus, d + nbins, (size_t)nbins * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_bins: kernel or copy failed"));
     return done(APS_OK);
 }
 

@@ -170,6 +170,11 @@ int aps_observe_scalars_all(aps_handle *h, int32_t x_wall, const int32_t *range_
  * (np.fft.fft(total)[k] times n dx).  out holds 4 + 2 k_max doubles; 1 <= k_max <= L. */
 int aps_observe_structure(aps_handle *h, int32_t ensemble, int32_t k_max, double *out);
 
+/* Coarse-grained histograms on the device: live plus / minus particles per bin of ceil(L / nbins) consecutive sites (the grid
+ * of the hydrodynamic-limit PDE when particle and PDE densities are compared on the same domain; rho_+- of ref :205-213
+ * summed over a bin).  plus, minus: [nbins] exact counts. */
+int aps_observe_bins(aps_handle *h, int32_t ensemble, int32_t nbins, int64_t *plus, int64_t *minus);
+
 /* m-field for a caller-supplied histogram: compute_local_m_field(counts_p, counts_m) (ref :216-246) */
 int aps_field_from_counts(aps_handle *h, int32_t ensemble, const int64_t *counts_p, const int64_t *counts_m,
                           double *m_field);

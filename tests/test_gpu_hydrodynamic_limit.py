@@ -57,3 +57,30 @@ def test_particle_ensemble_density_matches_pde_at_beta_zero():
     # the comparison is not vacuous: the profile has moved and spread
     com0, com1 = (snaps_tot[0] * np.arange(L)).sum() / snaps_tot[0].sum(), (snaps_tot[-1] * np.arange(L)).sum() / snaps_tot[-1].sum()
     assert (com1 - com0) * dx > 0.12                           # drift ~ lam / 2 * T = 0.18
+
+
+def test_config5_particles_against_pde_at_full_size():
+    """BASELINE config 5 at size: N ~ 1e6 particles on L = 2e6 sites (fixed-dt stepper, tiles formulation) against
+    IMEXPDE(bc="neumann", active_model="anchored_minus", gaussian_kernel=True, kernel_sigma=0.005) on L_pde = 1000 cells,
+    both on the GPU, coarse-grained on the device (aps_observe_bins), from the same initial densities
+    (tools/compare_hydrodynamic.py: parameter mapping, normalisation and the gamma convention are stated there).
+    The magnetisation profile m(x, t) relaxes under the Curie-Weiss reaction through the smoothing kernel; particles and PDE
+    must agree within the sampling noise of ~1000 particles per cell plus the O(dt) bias of both schemes, at every snapshot;
+    the density does not move on the PDE grid at this L (no exclusion term needed for that)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import compare_hydrodynamic as ch
+    for beta, grows in ((0.7, False), (1.6, True)):
+        res = ch.compare(L=2_000_000, L_pde=1000, T=1.0, beta=beta)
+        assert 0.98e6 < res["N"] < 1.02e6 and len(res["rows"]) >= 4
+        noise = res["sampling_noise_m"]                       # ~0.032
+        first, last = res["rows"][0], res["rows"][-1]
+        assert first["m_l2"] < 1e-12 and first["rho_l2_rel"] < 1e-12          # same initial densities
+        for row in res["rows"]:
+            assert row["m_l2"] < 1.5 * noise and row["m_max_dev"] < 6 * noise, (beta, row)
+            assert row["rho_l2_rel"] < 0.01, (beta, row)      # nothing moves on the PDE grid; particle counts per cell are conserved up to hops across cell borders
+            assert abs(row["m_amplitude_particles"] - row["m_amplitude_pde"]) < 0.02, (beta, row)
+        # the comparison is not vacuous: the cos(2 pi x) mode has relaxed (beta < 1) or grown (beta > 1) by a sizeable factor
+        ratio = last["m_amplitude_pde"] / first["m_amplitude_pde"]
+        assert (ratio > 1.15) if grows else (ratio < 0.8), (beta, ratio)

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: the particle system at N ~ 1e6 against the hydrodynamic-limit PDE on the same domain, both on the GPU.
+
+    python tools/compare_hydrodynamic.py [--L 2000000] [--L-pde 1000] [--T 1.0] [--beta 0.7] [--json out.json]
+
+Particles: L sites on [0, 1), K = 1, reflecting walls, sigma = 0.005, rate_active = 5, rate_diffusion = 0.02 (lattice units,
+scale_rates=False as in every BASELINE configuration), fixed dt = 0.0125, tiles formulation.  Initial condition: a site is
+occupied with probability rho(x) = 0.5 (1 + 0.4 cos 4 pi x), its spin is +1 with probability (1 + 0.6 cos 2 pi x) / 2 -- both
+even about the walls and 1-periodic, so the reference PDE's circular Gaussian kernel (IMEX_PDE_solver_class.py:84-93) and the
+particle class's reflecting one (PARTICLE_solver_CLASS.py:229-238) smooth them identically.
+
+PDE (IMEX_PDE_solver_class.py:187-233 on the GPU, package file pde.py): L_pde cells, bc="neumann", active_model="anchored_minus",
+gaussian_kernel=True, kernel_sigma=0.005, started from the particles' own coarse-grained initial densities; parameter mapping
+of PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py:351-353: lam = rate_active * dx, gamma = rate_diffusion * dx^2 with the
+PARTICLE dx.  (The reference's fit code writes 0.5 * rate_diffusion * dx^2: that is the convention of its closed-form D_eff
+curves; a lattice walk hopping at rate r to either side has D = r dx^2, which is what makes the beta = 0 test of
+tests/test_gpu_hydrodynamic_limit.py agree within sampling error.  At L = 2e6 both are ~1e-15: transport is negligible on the
+PDE grid over T ~ 1 either way, the comparison is about the mean-field reaction under the smoothing kernel.)
+Normalisation: the PDE keeps sum(rho+ + rho-) = 1 (:117-119), the particle class sum(total) dx = 1 (:209-213); the PDE
+densities are divided by dx_pde before comparing.  The PDE has NO exclusion term: agreement of the total density is expected
+only while transport is negligible or rho / K << 1; the magnetisation m = (rho+ - rho-) / (rho+ + rho-) is the quantity the
+reaction term drives and the one to look at.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
+
+
+def initial_condition(L, seed):
+    rng = np.random.default_rng(seed)
+    x = (np.arange(L) + 0.5) / L
+    occupied = rng.random(L) < 0.5 * (1.0 + 0.4 * np.cos(4 * np.pi * x))
+    pos = np.flatnonzero(occupied).astype(np.int32)
+    plus = rng.random(len(pos)) < 0.5 * (1.0 + 0.6 * np.cos(2 * np.pi * x[pos]))
+    order = rng.permutation(len(pos))                           # particle index carries no spatial information
+    return pos[order], np.where(plus, 1, -1).astype(np.int8)[order]
+
+
+def compare(L=2_000_000, L_pde=1000, T=1.0, beta=0.7, sigma=0.005, rate_active=5.0, rate_diffusion=0.02, dt=0.0125,
+            dt_pde=5e-4, seed=0, n_obs=4, device=0):
+    capi = importlib.import_module(PKG + ".capi")
+    pde = importlib.import_module(PKG + ".pde")
+    assert L % L_pde == 0
+    dx, dx_pde = 1.0 / L, 1.0 / L_pde
+    pos, spin = initial_condition(L, seed)
+    N = len(pos)
+    h = capi.Handle(L=L, K=1, periodic=False, sigma_grid=sigma / dx, rate_diffusion=rate_diffusion, rate_active=rate_active,
+                    beta=[beta], dt=dt, seed=seed, n_particles=N, device=device)
+    try:
+        h.set_state(pos, spin)
+        cp0, cm0 = h.observe_bins(L_pde)
+        # ---- PDE from the particles' coarse-grained initial densities
+        s = pde.IMEXPDE(L=L_pde, xlim=1.0, T=T + 0.5 * dt_pde, dt=dt_pde, gamma=rate_diffusion * dx * dx, lam=rate_active * dx, beta=beta,
+                        bc="neumann", active_model="anchored_minus", gaussian_kernel=True, kernel_sigma=sigma,
+                        snapshot_interval=max(1, int(round(T / dt_pde / n_obs))), seed=1, record_fft=False)
+        s.initialize(mode="homogeneous", rho0=1.0, noise=0.0, n_tracers=16)
+        s.rho_p, s.rho_m = cp0 / float(N), cm0 / float(N)
+        t0 = time.perf_counter()
+        s.solve()
+        t_pde = time.perf_counter() - t0
+        snaps_tot, snaps_mag = np.array(s.snapshots) / dx_pde, np.array(s.m_snapshots) / dx_pde      # rho, rho+ - rho- per unit length
+        # ---- particles, observed at the PDE's snapshot times
+        rows, done = [], 0
+        t0 = time.perf_counter()
+        for k in range(len(snaps_tot)):
+            t_k = k * s.snapshot_interval * dt_pde
+            want = int(round(t_k / dt))
+            h.step(want - done)
+            done = want
+            cp, cm = h.observe_bins(L_pde)
+            rho = (cp + cm) / (N * dx_pde)
+            m = (cp - cm) / np.maximum(cp + cm, 1)
+            m_pde = snaps_mag[k] / np.maximum(snaps_tot[k], 1e-300)
+            rows.append(dict(t=t_k, steps=done, rho_max_dev=float(np.max(np.abs(rho - snaps_tot[k]))),
+                             rho_l2_rel=float(np.sqrt(np.mean((rho - snaps_tot[k]) ** 2)) / np.mean(snaps_tot[k])),
+                             m_max_dev=float(np.max(np.abs(m - m_pde))), m_l2=float(np.sqrt(np.mean((m - m_pde) ** 2))),
+                             m_amplitude_particles=float(2 * np.mean(m * np.cos(2 * np.pi * (np.arange(L_pde) + 0.5) / L_pde))),
+                             m_amplitude_pde=float(2 * np.mean(m_pde * np.cos(2 * np.pi * (np.arange(L_pde) + 0.5) / L_pde)))))
+        t_part = time.perf_counter() - t0
+    finally:
+        h.close()
+    per_cell = N / L_pde
+    return dict(N=N, L=L, L_pde=L_pde, T=T, beta=beta, dt=dt, dt_pde=dt_pde, method="tiles", particles_per_cell=per_cell,
+                sampling_noise_m=float(1.0 / np.sqrt(per_cell)), gamma_convention="gamma = rate_diffusion * dx^2 (lattice walk: D = r dx^2)",
+                lam=rate_active * dx, gamma=rate_diffusion * dx * dx, caveat="the PDE has no exclusion term; transport is negligible on the PDE grid at this L",
+                wall_s_particles=t_part, wall_s_pde=t_pde, rows=rows)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=2_000_000)
+    ap.add_argument("--L-pde", type=int, default=1000)
+    ap.add_argument("--T", type=float, default=1.0)
+    ap.add_argument("--beta", type=float, default=0.7)
+    ap.add_argument("--json", default="")
+    a = ap.parse_args()
+    res = compare(L=a.L, L_pde=a.L_pde, T=a.T, beta=a.beta)
+    print(json.dumps(res, indent=1))
+    if a.json:
+        with open(a.json, "w") as fh:
+            json.dump(res, fh, indent=1)
