@@ -1,6 +1,10 @@
 """Batched beta sweeps: the reference's `sweep_beta_ensemble` / `sweep_over_betas` loops
 (PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta.py:56-117, :828-1028) with every (beta, run) pair stepped
-together as independent ensembles of one GPU handle, and the per-run observables of observables.py."""
+together as independent ensembles of one GPU handle, and the per-run observables of observables.py.
+The two outer sweeps of the other drivers are here too: `sweep_over_sigmas` (interaction range,
+..._sweep_beta_2.py:1030-1075) and `sweep_over_densities` (particle number x beta, ..._double_sweep.py:851-861) --
+one batched handle per sigma / per particle number (the weight table and the state capacity differ), all (beta, run)
+pairs inside it."""
 from __future__ import annotations
 
 import numpy as np
@@ -67,3 +71,36 @@ def sweep_beta_ensemble(beta, n_runs=10, ps_kwargs=None, init_kwargs=None, run_k
             float(r["m_means"][0]), float(r["m_stds"][0]), float(r["m_ses"][0]), float(r["rho_means"][0]),
             float(r["rho_ses"][0]), float(r["block_means"][0]), float(r["block_ses"][0]), float(r["D_means"][0]),
             float(r["D_ses"][0]))
+
+
+def sweep_over_sigmas(sigma_values, beta_values, n_runs_per_beta=5, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
+                      rng_seeds=None, on_device=False, dynamics="sync"):
+    """The sigma sweep of PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta_2.py:1030-1075: for every interaction range
+    `local_kernel_sigma` a whole beta sweep (one GPU handle per sigma: the weight table changes; sigma = 0 selects the global
+    mean field, sigma wider than the box the folded table).  Returns {sigma: {"beta", "v_mean", "v_se", "D_mean", "D_se",
+    "ps_kwargs"}} like the reference (which also writes one .npz per sigma; saving is left to the caller)."""
+    results = {}
+    for sigma in sigma_values:
+        kw = dict(ps_kwargs or {}, local_kernel_sigma=float(sigma))
+        r = sweep_over_betas(beta_values, n_runs_per_beta, kw, init_kwargs, run_kwargs, rng_seeds, on_device=on_device, dynamics=dynamics)
+        results[sigma] = {"beta": np.asarray(beta_values, dtype=float), "v_mean": r["means"], "v_se": r["ses"], "D_mean": r["D_means"],
+                          "D_se": r["D_ses"], "m_mean": r["m_means"], "block_mean": r["block_means"], "ps_kwargs": kw}
+    return results
+
+
+def sweep_over_densities(n_part_values, beta_values, n_runs_per_beta=4, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
+                         rng_seeds=None, on_device=False, dynamics="sync"):
+    """The density x beta double sweep of PARTICLE_solver_BIOLOGY_EXCLUSION_double_sweep.py:851-861
+    (`list_N_part = np.linspace(50, 950, 19)`: N arrives as a float there and is used as an integer): one batched beta sweep
+    per particle number.  Returns a list of the per-N sweep dictionaries (keys of `sweep_over_betas`) with "N_part" added;
+    the reference's fit of the blocking coefficients f, g to them (`rho_model`, :290-317) is closed-form SciPy on these
+    numbers and stays with the caller."""
+    out = []
+    for n_part in n_part_values:
+        if float(n_part) != int(n_part):
+            raise ValueError("particle numbers must be integral")
+        ik = dict(init_kwargs or {}, N=int(n_part))
+        r = sweep_over_betas(beta_values, n_runs_per_beta, ps_kwargs, ik, run_kwargs, rng_seeds, on_device=on_device, dynamics=dynamics)
+        r["N_part"] = int(n_part)
+        out.append(r)
+    return out

@@ -354,3 +354,27 @@ def test_structure_observables_on_device_equal_host_function():
                 np.testing.assert_allclose(d[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
             np.testing.assert_allclose(d["fft_mean"], ref["fft_mean"], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(d["fft_std"], ref["fft_std"], rtol=1e-8, atol=1e-9)
+
+
+def test_sigma_sweep_and_density_sweep_drivers():
+    """ensemble.sweep_over_sigmas / sweep_over_densities (the outer loops of ..._sweep_beta_2.py:1030-1075 and
+    ..._double_sweep.py:851-861): result shapes and keys, sigma = 0 (global field) and sigma wider than the box included;
+    a batched entry equals the same sweep run on its own (same seeds -> same numbers); more particles -> more blocking."""
+    ens = importlib.import_module(PKG + ".ensemble")
+    ps_kw = dict(L=300, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, scale_rates=False, site_capacity=1, k_on=0.0, k_off=0.0, k_exit=0.0,
+                 periodic=False, dt=0.0125, seed=5)
+    run_kw = dict(T=6.0, obs_dt=0.1)
+    betas = [0.0, 1.5, 3.0]
+    seeds = [[100 * b + r for r in range(2)] for b in range(len(betas))]
+    res = ens.sweep_over_sigmas([0.02, 0.5, 0.0], betas, n_runs_per_beta=2, ps_kwargs=ps_kw, init_kwargs=dict(init="fixed", N=150),
+                                run_kwargs=run_kw, rng_seeds=seeds)
+    assert list(res) == [0.02, 0.5, 0.0]
+    for sig, r in res.items():
+        assert r["v_mean"].shape == (3,) and r["v_se"].shape == (3,) and r["D_mean"].shape == (3,) and r["ps_kwargs"]["local_kernel_sigma"] == sig
+        assert np.all(np.isfinite(r["v_mean"]))
+    alone = ens.sweep_over_betas(betas, 2, dict(ps_kw, local_kernel_sigma=0.5), dict(init="fixed", N=150), run_kw, seeds)
+    assert np.array_equal(alone["means"], res[0.5]["v_mean"]) and np.array_equal(alone["D_means"], res[0.5]["D_mean"])
+    dens = ens.sweep_over_densities(np.array([60.0, 240.0]), betas, n_runs_per_beta=2, ps_kwargs=dict(ps_kw, local_kernel_sigma=0.02),
+                                    init_kwargs=dict(init="fixed"), run_kwargs=run_kw, rng_seeds=seeds)
+    assert [d["N_part"] for d in dens] == [60, 240] and all(d["means"].shape == (3,) for d in dens)
+    assert np.all(dens[1]["block_means"] > dens[0]["block_means"])          # a denser lattice blocks more hops
