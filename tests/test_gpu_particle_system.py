@@ -349,7 +349,8 @@ def test_structure_observables_on_device_equal_host_function():
         outs = psys.run_batched(systems(), T=3.0, obs_dt=0.1, record_fft=True, record_var=True)
         for d, out in zip(dev, outs):
             ref = obs.structure_observables(out, start_fraction=0.4, k_max=k_max)
-            assert d["dominant_k"] == ref["dominant_k"]
+            fold = lambda k: min(k, kw["L"] - k)               # |fft| of a real signal: modes k and L - k tie up to round-off
+            assert fold(d["dominant_k"]) == fold(ref["dominant_k"])
             for k in ("var_mean", "var_std", "low_k_power", "m_local_var", "lowk_variance"):
                 np.testing.assert_allclose(d[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
             np.testing.assert_allclose(d["fft_mean"], ref["fft_mean"], rtol=1e-9, atol=1e-9)
