@@ -38,7 +38,7 @@ class ApsParams(C.Structure):
         ("k_off", C.c_double), ("k_exit", C.c_double), ("dt", C.c_double), ("seed", C.c_uint64),
         ("beta", C.POINTER(C.c_double)), ("anchor_mask", C.POINTER(C.c_uint8)), ("device", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("sort_by_site", C.c_int32),
-        ("ensemble_base", C.c_int32), ("method", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("ensemble_base", C.c_int32), ("method", C.c_int32), ("fp32", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -139,7 +139,7 @@ class Handle:
     def __init__(self, *, L, K, periodic, sigma_grid, rate_diffusion, rate_active, beta, dt, seed,
                  n_particles, minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False,
                  k_on=0.0, k_off=0.0, k_exit=0.0, anchor_mask=None, device=0, rank=0, world=1,
-                 sort_by_site=True, ensemble_base=0, method="auto"):
+                 sort_by_site=True, ensemble_base=0, method="auto", fp32=False):
         self.lib = load()
         self._h = C.c_void_p()
         betas = np.atleast_1d(np.asarray(beta, dtype=np.float64)).copy()
@@ -157,7 +157,8 @@ class Handle:
                         beta=betas.ctypes.data_as(C.POINTER(C.c_double)),
                         anchor_mask=None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_uint8)),
                         device=int(device), rank=int(rank), world=int(world),
-                        sort_by_site=int(bool(sort_by_site)), ensemble_base=int(ensemble_base), method=METHODS[method])
+                        sort_by_site=int(bool(sort_by_site)), ensemble_base=int(ensemble_base), method=METHODS[method],
+                        fp32=int(bool(fp32)))
         rc = self.lib.aps_create(C.byref(par), C.byref(self._h))
         if rc != APS_OK:
             raise ApsError(rc, self.lib.aps_last_error(None).decode())

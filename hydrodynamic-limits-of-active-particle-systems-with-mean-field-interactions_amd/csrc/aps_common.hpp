@@ -108,7 +108,8 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
 // reflected images folded in, rounded to the grid 2^-q that keeps every possible partial sum exact.
 // Weight table (DESIGN.md "Weight table"): unnormalised taps of gaussian_filter1d(truncate=4) with the
 // reflected images folded in, rounded to the grid 2^-q that keeps every possible partial sum exact.
-inline void weight_table(double sigma_grid, int L_, int K, bool periodic, std::vector<double> &table, int &tlen, int &q_out) {
+// sum_bits: bits a sum of weights may take in grid units (51: exact binary64 field; 29: the int32 field of the fp32 mode)
+inline void weight_table(double sigma_grid, int L_, int K, bool periodic, std::vector<double> &table, int &tlen, int &q_out, int sum_bits = 51) {
     struct { double sigma_grid; int L, K; bool periodic; } p{sigma_grid, L_, K, periodic};
     table.clear();
     q_out = 0;
@@ -141,7 +142,7 @@ inline void weight_table(double sigma_grid, int L_, int K, bool periodic, std::v
     const double bound = std::ceil(nterm * wmax);
     int bits = 0;
     while (std::ldexp(1.0, bits) <= bound) ++bits;
-    int q = std::min(45, 51 - bits);
+    int q = std::min(45, sum_bits - bits);
     const double up = std::ldexp(1.0, q), down = std::ldexp(1.0, -q);
     int n = 0;
     for (int64_t t = 0; t <= tmax; ++t) {

@@ -1183,6 +1183,16 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
 
 #include "tile_step.hpp"
 
+// fp32 mode: the field as the tile kernel keeps it (int32, units of 2^-q) <-> the binary64 view of the other kernels; exact both ways
+__global__ __launch_bounds__(256) void ws_to_int(const double2 *__restrict__ in, int2 *__restrict__ out, size_t n, double up) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const double2 v = in[i]; out[i] = make_int2((int)(v.x * up), (int)(v.y * up)); }
+}
+__global__ __launch_bounds__(256) void ws_to_double(const int2 *__restrict__ in, double2 *__restrict__ out, size_t n, double down) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int2 v = in[i]; out[i] = make_double2((double)v.x * down, (double)v.y * down); }
+}
+
 // streaming copy, 16 bytes per lane: the HBM ceiling this box reaches in practice (bench.py quotes it beside the 8 TB/s spec)
 __global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1358,6 +1368,10 @@ struct aps_handle {
     long long *d_gpart[2] = {nullptr, nullptr};
     uint32_t *d_slot_of = nullptr;
     Model *d_model = nullptr; TileRare *d_rare = nullptr;      // device copies read by the tile kernel
+    // fp32 mode: the tile kernel's field is int32 in units of 2^-q; d_wsb then serves as the double2 view the hooks read
+    bool f32 = false, ws_view_stale = false;
+    int *d_table_i = nullptr;
+    int2 *d_wsi[2] = {nullptr, nullptr};
     // site-range sharding of the tiles formulation: this rank steps tiles [ts_lo, ts_hi) = sites [own_lo, own_hi)
     int ts_lo = 0, ts_hi = 0, own_lo = 0, own_hi = 0, ts_reach = 0;
     int ts_RS = 2, ts_own = 124, ts_ntile = 0, ts_dcap = 0;
@@ -1428,7 +1442,7 @@ struct Rccl {
     }
 } g_rccl;
 
-void build_table(aps_handle *h) { weight_table(h->p.sigma_grid, h->p.L, h->p.K, h->p.periodic != 0, h->table, h->tlen, h->q); }
+void build_table(aps_handle *h) { weight_table(h->p.sigma_grid, h->p.L, h->p.K, h->p.periodic != 0, h->table, h->tlen, h->q, h->p.fp32 ? 29 : 51); }
 
 template <typename T>
 int dev_alloc(aps_handle *h, T **ptr, size_t count) {
@@ -1730,14 +1744,20 @@ int launch_field_update(aps_handle *h) {
 // ------------------------------------------------------------------------------- tiles formulation, host side
 bool is_tiles(const aps_handle *h) { return h->method == APS_METHOD_TILES; }
 
-const void *ts_kernel(bool periodic, bool tab, int RS, bool k1) {
-#define TS_PICK(BC, TL, R) (k1 ? (const void *)&tile_step<BC, TL, R, true> : (const void *)&tile_step<BC, TL, R, false>)
+template <bool F32>
+const void *ts_kernel_f(bool periodic, bool tab, int RS, bool k1) {
+#define TS_PICK(BC, TL, R) (k1 ? (const void *)&tile_step<BC, TL, R, true, F32> : (const void *)&tile_step<BC, TL, R, false, F32>)
 #define TS_CASE(R) case R: return periodic ? (tab ? TS_PICK(1, true, R) : TS_PICK(1, false, R)) : (tab ? TS_PICK(0, true, R) : TS_PICK(0, false, R));
     switch (RS) { TS_CASE(1) TS_CASE(2) TS_CASE(3) TS_CASE(4) TS_CASE(5) TS_CASE(6) TS_CASE(7) TS_CASE(8) default: return nullptr; }
 #undef TS_CASE
 #undef TS_PICK
 }
+const void *ts_kernel(bool periodic, bool tab, int RS, bool k1, bool f32 = false) {
+    return f32 ? ts_kernel_f<true>(periodic, tab, RS, k1) : ts_kernel_f<false>(periodic, tab, RS, k1);
+}
 constexpr int TS_RS_CHOICES[] = {1, 2, 3, 4, 5, 6, 7, 8};
+
+int ts_wbytes(const aps_handle *h) { return h->f32 ? 4 : 8; }
 
 // tile geometry (measured on MI355X, profiles/r02_*): while the whole grid is resident at once (<= 3 workgroups per CU)
 // the frame that gives about 2.4 workgroups per CU is fastest (64 * 5 sites at L = 2e5); larger grids run in waves of
@@ -1759,7 +1779,7 @@ void ts_choose_geometry(aps_handle *h) {
     if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
-    h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K).total <= 160 * 1024;
+    h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total <= 160 * 1024;
     // site-range sharding: contiguous, balanced tile ranges; `reach` = tiles beyond a tile whose deposits can reach its frame
     h->ts_lo = (int)((int64_t)h->rank * h->ts_ntile / h->world);
     h->ts_hi = (int)((int64_t)(h->rank + 1) * h->ts_ntile / h->world);
@@ -1775,7 +1795,8 @@ TileArgs tile_args(aps_handle *h, bool field_only) {
     a.tile_lo = h->ts_lo; a.field_only = field_only ? 1 : 0; a.field_mode = h->model.field_mode; a.ens_base = h->model.ens_base; a.E = h->E;
     a.seed_lo = h->model.seed_lo; a.seed_hi = h->model.seed_hi;
     a.model = h->d_model; a.rare = h->d_rare;
-    a.ws_in = h->d_wsb[par]; a.ws_out = h->d_wsb[out];
+    a.ws_in = h->f32 ? (const void *)h->d_wsi[par] : (const void *)h->d_wsb[par];
+    a.ws_out = h->f32 ? (void *)h->d_wsi[out] : (void *)h->d_wsb[out];
     a.cell_in = h->d_cell[par]; a.cell_out = h->d_cell[par ^ 1];
     a.dcnt_in = h->d_tdcnt[par]; a.dep_in = h->d_tdep[par]; a.dcnt_out = h->d_tdcnt[par ^ 1]; a.dep_out = h->d_tdep[par ^ 1];
     a.gpart_in = h->d_gpart[par]; a.gpart_out = h->d_gpart[par ^ 1];
@@ -1792,9 +1813,10 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
         t0 = h->p.periodic ? t0 - 1 : std::max(0, t0 - 1);
         t1 = h->p.periodic ? t1 + 1 : std::min(h->ts_ntile, t1 + 1);
     }
-    const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1);
-    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K).total;
-    void *args[] = {(void *)&a, (void *)&h->d_table};
+    const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1, h->f32);
+    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total;
+    const void *table_ptr = h->f32 ? (const void *)h->d_table_i : (const void *)h->d_table;
+    void *args[] = {(void *)&a, (void *)&table_ptr};
     // a range that wraps around the torus (flush of a sharded periodic handle) is launched in pieces
     struct Piece { int lo, hi; } pieces[3];
     int np = 0;
@@ -1811,6 +1833,7 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
             HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, lds, h->stream));
     }
     if (!field_only) { h->slots_dirty = true; h->field_pending = true; }
+    h->ws_view_stale = true;
     return APS_OK;
 }
 
@@ -1829,7 +1852,7 @@ void halo_segments(const aps_handle *h, int owner_lo_tile, int owner_hi_tile, in
         const int t0 = side == 0 ? owner_lo_tile : owner_hi_tile - nt, t1 = t0 + nt;
         out.push_back({((size_t)e * L + c0) * K * 4, (size_t)(c1 - c0) * K * 4, 0});
         if (h->model.field_mode) {
-            out.push_back({((size_t)e * L + w0) * sizeof(double2), (size_t)(w1 - w0) * sizeof(double2), 1});
+            out.push_back({((size_t)e * L + w0) * 2 * ts_wbytes(h), (size_t)(w1 - w0) * 2 * ts_wbytes(h), 1});
             out.push_back({((size_t)e * h->ts_ntile + t0) * 4, (size_t)(t1 - t0) * 4, 2});
             out.push_back({((size_t)e * h->ts_ntile + t0) * h->ts_dcap * 4, (size_t)(t1 - t0) * h->ts_dcap * 4, 3});
         }
@@ -1839,7 +1862,7 @@ void halo_segments(const aps_handle *h, int owner_lo_tile, int owner_hi_tile, in
 char *halo_array(aps_handle *h, int array, int buf) {
     switch (array) {
         case 0: return reinterpret_cast<char *>(h->d_cell[buf]);
-        case 1: return reinterpret_cast<char *>(h->d_wsb[buf]);
+        case 1: return h->f32 ? reinterpret_cast<char *>(h->d_wsi[buf]) : reinterpret_cast<char *>(h->d_wsb[buf]);
         case 2: return reinterpret_cast<char *>(h->d_tdcnt[buf]);
         default: return reinterpret_cast<char *>(h->d_tdep[buf]);
     }
@@ -1902,8 +1925,15 @@ int sync_slots(aps_handle *h) {
     if (rc) return rc;
     const int cur = (int)(h->step & 1);
     h->d_ws = h->d_wsb[cur];
-    if (!h->slots_dirty) return APS_OK;
     const int L = h->p.L;
+    if (h->f32 && h->model.field_mode && h->ws_view_stale) {      // the hooks read the binary64 view of the integer field
+        const size_t n = (size_t)h->E * L;
+        hipLaunchKernelGGL(ws_to_double, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_wsi[cur], h->d_wsb[cur], n, std::ldexp(1.0, -h->q));
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->ws_view_stale = false;
+    }
+    if (!h->slots_dirty) return APS_OK;
     const int s_lo = h->world > 1 ? h->own_lo : 0, s_hi = h->world > 1 ? h->own_hi : L;
     if (h->world > 1)
         hipLaunchKernelGGL(mark_away, dim3((unsigned)(((size_t)h->E * h->Npad + 255) / 256)), dim3(256), 0, h->stream, h->d_src, (size_t)h->E * h->Npad);
@@ -1934,6 +1964,11 @@ int ensure_tiles(aps_handle *h) {
                                   nullptr, h->d_wsb[cur] + (size_t)e * L);
             if (rc) return rc;
         }
+    if (h->f32 && h->model.field_mode) {
+        const size_t n = (size_t)h->E * L;
+        hipLaunchKernelGGL(ws_to_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_wsb[cur], h->d_wsi[cur], n, std::ldexp(1.0, h->q));
+        h->ws_view_stale = false;
+    }
     HIP_TRY(h, hipMemsetAsync(h->d_tdcnt[cur], 0, (size_t)h->E * h->ts_ntile * 4, h->stream));
     long long *gs = h->d_gsum + (size_t)cur * 2 * h->E;
     HIP_TRY(h, hipMemsetAsync(gs, 0, (size_t)2 * h->E * sizeof(long long), h->stream));
@@ -2075,6 +2110,8 @@ int aps_create(const aps_params *p, aps_handle **out) {
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "lattice")) h->method = APS_METHOD_LATTICE;
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "tiles") && tiles_ok) h->method = APS_METHOD_TILES;
         }
+        h->f32 = p->fp32 != 0 && h->method == APS_METHOD_TILES;
+        if (p->fp32 && M.field_mode && h->q < 4) { delete h; return bad("fp32: the sums of this lattice do not fit a 32-bit field (q < 4)"); }
         ts_choose_geometry(h);
         // sites per lane of field_update: the largest tile that still gives about two workgroups per CU
         // sites per lane of field_update (tile = 64 * RS sites per workgroup): about 2.4 workgroups per CU was the
@@ -2144,10 +2181,18 @@ int aps_create(const aps_params *p, aps_handle **out) {
                 hipMemcpyAsync(h->d_rare, &rare, sizeof(TileRare), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "tile argument upload failed"; return die(APS_ERR_HIP); }
         }
-        const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K).total;
+        if (h->f32) {
+            std::vector<int> ti(h->table.size());
+            for (size_t i = 0; i < ti.size(); ++i) ti[i] = (int)std::ldexp(h->table[i], h->q);      // exact: multiples of 2^-q below 2^29
+            if ((rc = dev_alloc(h, &h->d_table_i, h->table.size() + ((size_t)1 << h->bshift) + 8192)) ||
+                (rc = dev_alloc(h, &h->d_wsi[0], EL)) || (rc = dev_alloc(h, &h->d_wsi[1], EL))) return die(rc);
+            if (hipMemcpyAsync(h->d_table_i, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "integer table upload failed"; return die(APS_ERR_HIP); }
+        }
+        const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K, ts_wbytes(h)).total;
         if (need > 160 * 1024) { h->err = "tiles: site capacity too large for the tile kernel's LDS staging"; return die(APS_ERR_ARG); }
         if (need > 48 * 1024 &&
-            hipFuncSetAttribute(ts_kernel(p->periodic != 0, h->ts_table_in_lds, h->ts_RS, p->K == 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
+            hipFuncSetAttribute(ts_kernel(p->periodic != 0, h->ts_table_in_lds, h->ts_RS, p->K == 1, h->f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
             h->err = "hipFuncSetAttribute(tile_step) failed"; return die(APS_ERR_HIP);
         }
     }
@@ -2173,7 +2218,7 @@ void aps_destroy(aps_handle *h) {
     if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
     for (int b = 0; b < 2; ++b)
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
-    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)h->d_wsi[1]}) if (q) (void)hipFree(q);
     for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_lo_hi, (void *)h->d_ref_ok, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
@@ -2420,7 +2465,7 @@ int aps_step(aps_handle *h, int64_t nsteps) {
                 HIP_TRY(h, hipGraphLaunch(h->gexec[g], h->stream));
                 h->step += GRAPH_SIZES[g];
                 h->last_graph_steps += GRAPH_SIZES[g];
-                if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; }
+                if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true; }
             }
     }
     for (; s < nsteps; ++s, ++h->last_single_steps)

@@ -33,7 +33,7 @@ struct TileArgs {
     uint32_t seed_lo, seed_hi;                         // Philox key
     const Model *model;                                // device copy of the rate parameters (read by the proposal phase)
     const TileRare *rare;
-    const double2 *ws_in; double2 *ws_out;             // [E][L]
+    const void *ws_in; void *ws_out;                   // [E][L] double2 {W, S}, or int2 in units of 2^-q (fp32 mode)
     const uint32_t *cell_in; uint32_t *cell_out;       // [E][L][K]
     const uint32_t *dcnt_in, *dep_in;                  // [E][ntile], [E][ntile][dcap]: written by the previous step
     uint32_t *dcnt_out, *dep_out;
@@ -47,13 +47,13 @@ struct TileArgs {
 template <bool TAB_LDS> struct TsGeom { static constexpr int SB = TAB_LDS ? 4 : 5, NSLOT = 1 << SB, GB = FU_WAVES * (64 >> SB); };
 
 __host__ __device__ inline int ts_table_pad(int RS, int own) { return 64 * RS + own + 2; }
-__host__ __device__ inline int ts_table_chunks(int tlen, int RS, int own) { return (tlen + ts_table_pad(RS, own) + 1 + 127) / 128; }   // 1 KB each
+__host__ __device__ inline int ts_table_chunks(int tlen, int RS, int own, int wbytes) { return ((tlen + ts_table_pad(RS, own) + 1) * wbytes + 1023) / 1024; }   // 1 KB each
 constexpr int TS_WH = 8;                   // windowed sweep: bucket offsets per group (buckets tile - off and tile + off, off in [jH, jH + H))
 __host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TS_WH + 1) * own + 64 * RS + 8 + 127) / 128 * 128; }
 constexpr int TS_SHCAP = 320;              // windowed sweep: capacity of a shared class list (a round adds at most 256 entries)
 constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
 struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
-__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K) {
+__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K, int wbytes = 8) {
     TsLds l;
     const size_t TS = 64 * (size_t)RS;
     const int ncell = (int)(TS + 2) * K;
@@ -66,13 +66,34 @@ __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, i
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
     l.plist = l.misc + 64;
     l.tab = (l.plist + (l.cells_in_regs ? (size_t)FU_WAVES * l.Q * 8 : 0) + 15) / 16 * 16;
-    const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own) * 1024 : (size_t)2 * ts_win_entries(RS, own) * sizeof(double);
-    const size_t red = (size_t)FU_WAVES * TS * sizeof(double2);
+    const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes;
+    const size_t red = (size_t)FU_WAVES * TS * 2 * wbytes;
     l.field = l.tab + red;                                      // fresh {W, S} of the frame sites, behind the partial sums
     const size_t after = red + TS * sizeof(double2);
     l.total = l.tab + (table > after ? table : after);
     return l;
 }
+
+// Field arithmetic.  F32 = false: binary64 weights on the grid 2^-q (q = 51 - bits of the largest possible sum): the exact
+// field every other formulation and the oracle use.  F32 = true (`fp32` flag of aps_params): the same construction on the
+// coarser grid that lets every sum fit a 32-bit integer (q = 29 - bits): weights, W and S are int32 in units of 2^-q --
+// float32-class accuracy (relative 1e-6 on m), still exact integer sums, hence still independent of summation order,
+// tiling and GPU count; half the LDS bytes per table read and integer multiply-adds instead of f64 fma.
+template <bool F32> struct TsField;
+template <> struct TsField<false> { using w_t = double; using ws_t = double2; static constexpr int SH = 3; };
+template <> struct TsField<true> { using w_t = int; using ws_t = int2; static constexpr int SH = 2; };
+
+template <bool TAB_LDS, typename W>
+__device__ __forceinline__ W ts_table_at(const W *__restrict__ table_g, uint32_t byte_addr) {
+    if (TAB_LDS) {
+        typedef __attribute__((address_space(3))) const W lds_cw;
+        return *reinterpret_cast<lds_cw *>(byte_addr);        // byte_addr already includes the table's LDS offset
+    }
+    return *reinterpret_cast<const W *>(reinterpret_cast<const char *>(table_g) + byte_addr);
+}
+
+__device__ __forceinline__ void ts_acc(double &acc, double w, int c) { acc = fma(w, (double)c, acc); }
+__device__ __forceinline__ void ts_acc(int &acc, int w, int c) { acc += w * c; }
 
 // |a - b| + c with b wave-uniform (a deposit's site * 8 in a scalar register)
 __device__ __forceinline__ uint32_t sad3s(uint32_t a, uint32_t b_uniform, uint32_t c) {
@@ -82,41 +103,44 @@ __device__ __forceinline__ uint32_t sad3s(uint32_t a, uint32_t b_uniform, uint32
 }
 
 // weights of four wave-uniform deposits at this lane's RS sites.  VAR 0: interior (padded LDS table or window: no clamp),
-// VAR 1: torus
-template <int VAR, bool TAB_LDS, int RS>
+// VAR 1: torus.  x8 / p8 / tlen8 / L8 are site numbers times the entry size (8 or 4 bytes).
+template <int VAR, bool TAB_LDS, int RS, bool F32>
 __device__ __forceinline__ void ts_weights(const uint32_t (&ent)[4], const uint32_t (&x8)[RS], const uint32_t tbase,
-                                           const double *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8, double (&w)[4][RS]) {
+                                           const typename TsField<F32>::w_t *__restrict__ table_g, const uint32_t tlen8, const uint32_t L8,
+                                           typename TsField<F32>::w_t (&w)[4][RS]) {
+    using W = typename TsField<F32>::w_t;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t p8 = (ent[k] & POS_MASK) << 3;
+        const uint32_t p8 = (ent[k] & POS_MASK) << TsField<F32>::SH;
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             if (VAR == 0) {
                 const uint32_t d = sad3s(x8[r], p8, tbase);
-                w[k][r] = table_at<TAB_LDS>(table_g, TAB_LDS ? d : min(d, tlen8));
+                w[k][r] = ts_table_at<TAB_LDS, W>(table_g, TAB_LDS ? d : min(d, tlen8));
             } else {
                 const uint32_t d8 = sad3s(x8[r], p8, 0u);
-                w[k][r] = table_at<TAB_LDS>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
+                w[k][r] = ts_table_at<TAB_LDS, W>(table_g, min(min(d8, L8 - d8), tlen8) + tbase);
             }
         }
     }
 }
 
 // four deposits of ONE class into ONE accumulator set: a deposit's (cW, cS) is (c, c) [class P: a plus particle came or
-// went], (c, -c) [class M: a minus particle] or (0, c) [class F: a flip], so one fma per table read does it.
+// went], (c, -c) [class M: a minus particle] or (0, c) [class F: a flip], so one multiply-add per table read does it.
 // MODE 0: coefficient = cW (classes P, M), MODE 1: coefficient = cS (class F).  W = P + M, S = P - M + F, all exact.
-template <int VAR, bool TAB_LDS, int RS, int MODE>
-__device__ __forceinline__ void ts_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase, const double *__restrict__ table_g,
-                                         const uint32_t tlen8, const uint32_t L8, double (&acc)[RS]) {
+template <int VAR, bool TAB_LDS, int RS, int MODE, bool F32>
+__device__ __forceinline__ void ts_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase,
+                                         const typename TsField<F32>::w_t *__restrict__ table_g,
+                                         const uint32_t tlen8, const uint32_t L8, typename TsField<F32>::w_t (&acc)[RS]) {
     const uint32_t ent[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
                              (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
-    double w[4][RS];
-    ts_weights<VAR, TAB_LDS, RS>(ent, x8, tbase, table_g, tlen8, L8, w);
+    typename TsField<F32>::w_t w[4][RS];
+    ts_weights<VAR, TAB_LDS, RS, F32>(ent, x8, tbase, table_g, tlen8, L8, w);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double c = MODE == 0 ? (double)((int)((ent[k] >> 27) & 3u) - 1) : (double)((int)(ent[k] >> 29) - 2);
+        const int c = MODE == 0 ? (int)((ent[k] >> 27) & 3u) - 1 : (int)(ent[k] >> 29) - 2;
 #pragma unroll
-        for (int r = 0; r < RS; ++r) acc[r] = fma(w[k][r], c, acc[r]);
+        for (int r = 0; r < RS; ++r) ts_acc(acc[r], w[k][r], c);
     }
 }
 
@@ -126,44 +150,52 @@ constexpr uint32_t TS_BIAS = 1u << 26;     // L <= 2^25 and reach <= L: every bi
 
 // small boxes only (reach comparable to L: a deposit's two wall images can both matter within one frame): direct term +
 // folded image term per lane, W and S accumulated separately
-template <bool TAB_LDS, int RS>
-__device__ __forceinline__ void ts_image_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase, const double *__restrict__ table_g,
-                                               const uint32_t tlen8, const uint32_t L8, double (&accW)[RS], double (&accS)[RS]) {
+template <bool TAB_LDS, int RS, bool F32>
+__device__ __forceinline__ void ts_image_group(const uint4 q, const uint32_t (&x8)[RS], const uint32_t tbase,
+                                               const typename TsField<F32>::w_t *__restrict__ table_g,
+                                               const uint32_t tlen8, const uint32_t L8, typename TsField<F32>::w_t (&accW)[RS],
+                                               typename TsField<F32>::w_t (&accS)[RS]) {
+    using W = typename TsField<F32>::w_t;
+    constexpr int SH = TsField<F32>::SH;
     const uint32_t ent[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
                              (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t p8 = (ent[k] & POS_MASK) << 3;            // biased, like x8
-        const double cw = (double)((int)((ent[k] >> 27) & 3u) - 1), cs = (double)((int)(ent[k] >> 29) - 2);
+        const uint32_t p8 = (ent[k] & POS_MASK) << SH;         // biased, like x8
+        const int cw = (int)((ent[k] >> 27) & 3u) - 1, cs = (int)(ent[k] >> 29) - 2;
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
-            const uint32_t s8 = x8[r] + p8 + 8u - 2u * (TS_BIAS << 3);   // (x + p + 1) * 8
-            const double w = table_at<TAB_LDS>(table_g, min(sad3s(x8[r], p8, 0u), tlen8) + tbase) +
-                             table_at<TAB_LDS>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
-            accW[r] = fma(w, cw, accW[r]);
-            accS[r] = fma(w, cs, accS[r]);
+            const uint32_t s8 = x8[r] + p8 + (1u << SH) - 2u * (TS_BIAS << SH);   // (x + p + 1) * entry size
+            const W w = ts_table_at<TAB_LDS, W>(table_g, min(sad3s(x8[r], p8, 0u), tlen8) + tbase) +
+                        ts_table_at<TAB_LDS, W>(table_g, min(min(s8, 2u * L8 - s8), tlen8) + tbase);
+            ts_acc(accW[r], w, cw);
+            ts_acc(accS[r], w, cs);
         }
     }
 }
 
 // K1: site capacity 1 (one cell per site): every loop over a site's cells disappears
-template <int BC, bool TAB_LDS, int RS, bool K1>
-__global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const double *__restrict__ table_g) {
+template <int BC, bool TAB_LDS, int RS, bool K1, bool F32>
+__global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const void *__restrict__ table_v) {
+    using W = typename TsField<F32>::w_t;
+    using WS = typename TsField<F32>::ws_t;
+    constexpr int SH = TsField<F32>::SH, WB = (int)sizeof(W);
+    const W *__restrict__ table_g = reinterpret_cast<const W *>(table_v);
     constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS;
     constexpr int SEG = TS_SEG;
     constexpr int SB = TsGeom<TAB_LDS>::SB, NSLOT = TsGeom<TAB_LDS>::NSLOT, GB = TsGeom<TAB_LDS>::GB;
     constexpr int NR = K1 ? ((TS + 2 + FU_WAVES - 1) / FU_WAVES + 63) / 64 : TS_CREG;   // register rounds of the wave's cell chunk
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
-    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K);
+    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K, WB);
     char *lds_c = reinterpret_cast<char *>(lds);
     uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
     uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
     uint8_t *propL = reinterpret_cast<uint8_t *>(lds_c + lay.props);         // [TS K]
     uint8_t *occL = reinterpret_cast<uint8_t *>(lds_c + lay.occ);            // [TS + 2]
     int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // 0 deposits of this tile, 1 spin sum, 2 live count, 4/5 global sums
-    double *tab = reinterpret_cast<double *>(lds_c + lay.tab);
-    double2 *red = reinterpret_cast<double2 *>(tab);
+    W *tab = reinterpret_cast<W *>(lds_c + lay.tab);
+    WS *red = reinterpret_cast<WS *>(tab);
     double2 *fieldL = reinterpret_cast<double2 *>(lds_c + lay.field);        // [TS]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
     uint32_t *segP = seg_all + wave * 4 * (SEG + 4), *segM = segP + SEG + 4, *segF = segM + SEG + 4, *segI = segF + SEG + 4;
@@ -175,13 +207,13 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     const int Rt = a.tlen - 1;
     // per-ensemble bases (scalar); everything below indexes them with 32-bit offsets
     const uint32_t *__restrict__ cell_e = a.cell_in + (size_t)e * L * K;
-    const double2 *__restrict__ ws_e = a.ws_in + (size_t)e * L;
+    const WS *__restrict__ ws_e = reinterpret_cast<const WS *>(a.ws_in) + (size_t)e * L;
     const uint32_t *__restrict__ dcnt_e = a.dcnt_in + (size_t)e * a.ntile;
     const uint32_t *__restrict__ dep_e = a.dep_in + (size_t)e * a.ntile * a.dcap;
     uint32_t tbase = 0;
     {
-        typedef __attribute__((address_space(3))) double lds_double;
-        tbase = (uint32_t)(size_t)(lds_double *)tab;          // LDS byte offset of the table (or of the windows)
+        typedef __attribute__((address_space(3))) W lds_w;
+        tbase = (uint32_t)(size_t)(lds_w *)tab;               // LDS byte offset of the table (or of the windows)
     }
 #ifdef APS_STAMPS
     unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_part = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
@@ -195,11 +227,11 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     // followed by zeros, so the padded tail comes along.  Written as inline assembly like the windows below (the compiler
     // would put an s_waitcnt vmcnt(0) in front of every later LDS read); the wait in front of the barrier orders it.
     if (TAB_LDS) {
-        const int nchunk = ts_table_chunks(a.tlen, RS, OWN);
-        const double *srct = table_g + lane * 2;
+        const int nchunk = ts_table_chunks(a.tlen, RS, OWN, WB);
+        const char *srct = reinterpret_cast<const char *>(table_g) + lane * 16;
         for (int c = wave; c < nchunk; c += FU_WAVES) {
             const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tbase + (uint32_t)c * 1024u));
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srct + c * 128) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srct + c * 1024) : "memory");
         }
     }
     const unsigned long long step = a.stepw[a.par];
@@ -271,13 +303,13 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         pre_ent[j] = dep_e[(unsigned)b * (unsigned)a.dcap + slot_c];
         if (!ok) pre_cnt[j] = 0u;
     }
-    double2 old[NOLD];
+    WS old[NOLD];
 #pragma unroll
     for (int r = 0; r < NOLD; ++r) {
         const int xi = r * FU_THREADS + t;
         const int s = (xi < TS && xi < nfr) ? frame_site(xi) : -1;
         old[r] = ws_e[(unsigned)max(s, 0)];
-        if (s < 0 || !a.field_mode) old[r] = make_double2(0.0, 0.0);
+        if (s < 0 || !a.field_mode) { old[r].x = 0; old[r].y = 0; }
     }
     // global-field mode (ref :219-221): the sums over all particles = sum of the tiles' parts
     long long gS = 0, gN = 0;
@@ -306,14 +338,14 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
 #pragma unroll
         for (int u = 0; u < NR; ++u) { const int c = c_lo + lane + 64 * u; if (c < c_hi) cellL[c] = creg[u]; }
     }
-    const uint32_t tlen8 = (uint32_t)a.tlen << 3, L8 = (uint32_t)L << 3;
+    const uint32_t tlen8 = (uint32_t)a.tlen << SH, L8 = (uint32_t)L << SH;
     uint32_t x8[RS];
-    double accP[RS], accM[RS], accF[RS], accWi[RS], accSi[RS];
+    W accP[RS], accM[RS], accF[RS], accWi[RS], accSi[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         int s = x0 + r * 64 + lane;
         if (BC == 1) { s %= L; if (s < 0) s += L; } else s = min(max(s, 0), L - 1);
-        x8[r] = ((uint32_t)s + TS_BIAS) << 3; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0.0;
+        x8[r] = ((uint32_t)s + TS_BIAS) << SH; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0;
     }
     if (TAB_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's table chunks have landed
     __syncthreads();                                           // table and cells staged
@@ -336,15 +368,15 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         uint4 q = SEG4[0]; \
         _Pragma("unroll 1") for (int i = 0; i < ((N) + 3) >> 2; ++i) { \
             const uint4 qn = SEG4[i + 1];                      /* next group's entries: in flight during this group's gathers */ \
-            if (BC == 1) ts_group<1, TAB_LDS, RS, MODE>(q, x8, tb, table_g, tlen8, L8, ACC); \
-            else ts_group<0, TAB_LDS, RS, MODE>(q, x8, tb, table_g, tlen8, L8, ACC); \
+            if (BC == 1) ts_group<1, TAB_LDS, RS, MODE, F32>(q, x8, tb, table_g, tlen8, L8, ACC); \
+            else ts_group<0, TAB_LDS, RS, MODE, F32>(q, x8, tb, table_g, tlen8, L8, ACC); \
             q = qn; } }
         TS_SWEEP(segP4, nP, 0, accP)
         TS_SWEEP(segM4, nM, 0, accM)
         TS_SWEEP(segF4, nF, 1, accF)
 #undef TS_SWEEP
 #pragma unroll 1
-        for (int i = 0; i < (nI + 3) >> 2; ++i) ts_image_group<TAB_LDS, RS>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
+        for (int i = 0; i < (nI + 3) >> 2; ++i) ts_image_group<TAB_LDS, RS, F32>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
 #ifdef APS_STAMPS
         f_n += nP + nM + nF + nI;
 #endif
@@ -376,11 +408,11 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         auto win_dmin = [&](int j) -> int { return max(0, min((j * H - 1) * OWN - 2, j * H * OWN + 2 - TS)); };
         auto stage_w = [&](int j) {
             const int dmin = win_dmin(j), span = max((j * H + H) * OWN + 2, (j * H + H - 1) * OWN + TS - 2) - dmin;
-            const double *srcw = table_g + dmin + lane * 2;
-            const uint32_t dstw = win_lds + (uint32_t)((j & 1) * WIN) * 8u;
-            for (int c = wave; c * 128 <= span; c += FU_WAVES) {
+            const char *srcw = reinterpret_cast<const char *>(table_g + dmin) + lane * 16;
+            const uint32_t dstw = win_lds + (uint32_t)((j & 1) * WIN) * (uint32_t)WB;
+            for (int c = wave; c * (1024 / WB) <= span; c += FU_WAVES) {
                 const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dstw + (uint32_t)c * 1024u));
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srcw + c * 128) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srcw + c * 1024) : "memory");
             }
         };
         stage_w(0);
@@ -413,7 +445,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             }
             __syncthreads();                                   // lists j complete, window j landed everywhere, everyone is done with group j - 1
             if (t == 0) { scnt[((j + 2) % 3) * 2] = 0; scnt[((j + 2) % 3) * 2 + 1] = 0; }   // nobody touches that pair before the next barrier
-            const uint32_t wbase = win_lds + (uint32_t)(jj * WIN) * 8u - ((uint32_t)win_dmin(j) << 3);
+            const uint32_t wbase = win_lds + (uint32_t)(jj * WIN) * (uint32_t)WB - ((uint32_t)win_dmin(j) << SH);
             const uint32_t padw = DEP_NULL | ((uint32_t)(j == 0 ? x0c : x1c + win_dmin(j)) + TS_BIAS);
             const uint32_t cnt_now = cnt;
             const int b_now = b;
@@ -436,7 +468,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                     const uint4 qn = l4[min(g + FU_WAVES, TS_SHCAP / 4 - 1)]; \
                     const int left = n_ - 4 * g;               /* entries beyond the list's end -> padding */ \
                     q.y = left > 1 ? q.y : padw; q.z = left > 2 ? q.z : padw; q.w = left > 3 ? q.w : padw; \
-                    ts_group<0, true, RS, MODE>(q, x8, wbase, table_g, tlen8, L8, ACC); \
+                    ts_group<0, true, RS, MODE, F32>(q, x8, wbase, table_g, tlen8, L8, ACC); \
                     q = qn; } \
                 rot = (rot - ng_) & 3; }
             TS_SHARED(0, 0, accP) TS_SHARED(1, 0, accM) TS_SHARED(2, 1, accF)
@@ -453,9 +485,9 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)en, src_lane);
                         const uint4 q1 = make_uint4(e1, padw, padw, padw);
                         const int cw = (int)((e1 >> 27) & 3u) - 1, cs = (int)(e1 >> 29) - 2;
-                        if (cw == 0) ts_group<0, true, RS, 1>(q1, x8, wbase, table_g, tlen8, L8, accF);
-                        else if (cw == cs) ts_group<0, true, RS, 0>(q1, x8, wbase, table_g, tlen8, L8, accP);
-                        else ts_group<0, true, RS, 0>(q1, x8, wbase, table_g, tlen8, L8, accM);
+                        if (cw == 0) ts_group<0, true, RS, 1, F32>(q1, x8, wbase, table_g, tlen8, L8, accF);
+                        else if (cw == cs) ts_group<0, true, RS, 0, F32>(q1, x8, wbase, table_g, tlen8, L8, accP);
+                        else ts_group<0, true, RS, 0, F32>(q1, x8, wbase, table_g, tlen8, L8, accM);
                     }
                 }
             }
@@ -512,7 +544,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     __syncthreads();                                           // every wave is done with the table: its space takes the partial sums
 #pragma unroll
     for (int r = 0; r < RS; ++r)                               // W = P + M, S = P - M + F (+ the image deposits), exact on the weight grid
-        red[(size_t)wave * TS + r * 64 + lane] = make_double2((accP[r] + accM[r]) + accWi[r], ((accP[r] - accM[r]) + accF[r]) + accSi[r]);
+        { WS v; v.x = (accP[r] + accM[r]) + accWi[r]; v.y = ((accP[r] - accM[r]) + accF[r]) + accSi[r]; red[(size_t)wave * TS + r * 64 + lane] = v; }
     // occupancy of the frame sites (-1 .. TS) from the staged cells
     for (int i = t; i < TS + 2; i += FU_THREADS) {
         int n = 0;
@@ -529,12 +561,12 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     for (int r = 0; r < NOLD; ++r) {
         const int xi = r * FU_THREADS + t;
         if (xi < TS && xi < nfr) {
-            double2 f = old[r];
+            WS f = old[r];
 #pragma unroll
-            for (int w = 0; w < FU_WAVES; ++w) { const double2 pth = red[(size_t)w * TS + xi]; f.x += pth.x; f.y += pth.y; }
-            if (!a.field_mode) f = make_double2((double)misc[5], (double)misc[4]);
-            fieldL[xi] = f;
-            if (a.field_mode && xi >= 2 && xi < 2 + own_n) a.ws_out[(size_t)e * L + (unsigned)frame_site(xi)] = f;
+            for (int w = 0; w < FU_WAVES; ++w) { const WS pth = red[(size_t)w * TS + xi]; f.x += pth.x; f.y += pth.y; }
+            // S / W does not care about the unit (2^-q in the integer field): the proposals read doubles either way
+            fieldL[xi] = a.field_mode ? make_double2((double)f.x, (double)f.y) : make_double2((double)misc[5], (double)misc[4]);
+            if (a.field_mode && xi >= 2 && xi < 2 + own_n) reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
         }
     }
     if (a.field_only) return;                                  // flush of the pending deposits only (observation)

@@ -51,7 +51,12 @@ typedef struct aps_params {
     int32_t sort_by_site;       /* 1: keep particles ordered by site internally (tile culling) */
     int32_t ensemble_base;      /* Philox counter word 3 of local ensemble e is ensemble_base + e */
     int32_t method;             /* APS_METHOD_*: which formulation of the mean field the stepper uses */
-    int32_t reserved[2];
+    int32_t fp32;               /* 0: exact binary64 field (weights on the grid 2^-q, q = 51 - bits of the largest sum).
+                                   1: "float32" field of BASELINE config 5: the same construction on the coarser grid on which
+                                   every sum fits 32 bits (q = 29 - bits); W, S and the table are int32 in the stepping kernel
+                                   (APS_METHOD_TILES).  Still exact integer sums -- independent of summation order, tiling and GPU
+                                   count -- but a different, coarser weight table: |m - m_reference| ~ 1e-6 instead of 2e-11 */
+    int32_t reserved[1];
 } aps_params;
 
 /* Two formulations of compute_local_m_field (ref :216-246); both give the same bits (exact weight grid):

@@ -101,8 +101,19 @@ double orc_exp(double x) {
  *   periodic:  W[t] = exp(-0.5 t^2 / sigma_g^2), t = circular distance, 0 <= t <= L/2       (ref :114-116)
  *   reflect :  W[t] = sum_k w(|t + 2Lk|), |t + 2Lk| <= lw,  t = circular distance mod 2L, 0 <= t <= L
  * Returns the number of entries written (trailing zeros trimmed), q in *q_out; -1 if cap too small. */
+/* sum_bits = bits a sum of weights may occupy in units of the grid: 51 for the exact binary64 field (two spare bits for
+ * add / subtract sequences of the incremental formulations), 29 for the 32-bit integer field of the library's `fp32` mode
+ * (same two spare bits under the int32 sign bit). */
+int32_t orc_build_table_bits(double sigma_g, int32_t L, int32_t K, int32_t periodic, int32_t sum_bits, double *out, int32_t cap,
+                             int32_t *q_out);
+
 int32_t orc_build_table(double sigma_g, int32_t L, int32_t K, int32_t periodic, double *out, int32_t cap,
                         int32_t *q_out) {
+    return orc_build_table_bits(sigma_g, L, K, periodic, 51, out, cap, q_out);
+}
+
+int32_t orc_build_table_bits(double sigma_g, int32_t L, int32_t K, int32_t periodic, int32_t sum_bits, double *out, int32_t cap,
+                             int32_t *q_out) {
     const double s2 = sigma_g * sigma_g;
     int64_t lw = periodic ? (int64_t)(L / 2) : (int64_t)(4.0 * sigma_g + 0.5);
     int64_t tmax = periodic ? (int64_t)(L / 2) : (lw < (int64_t)L ? lw : (int64_t)L);
@@ -132,7 +143,7 @@ int32_t orc_build_table(double sigma_g, int32_t L, int32_t K, int32_t periodic, 
     double bound = ceil(nterm * wmax);
     int bits = 0;
     while (ldexp(1.0, bits) <= bound) ++bits;       /* bit length of the integer bound */
-    int q = 51 - bits;
+    int q = sum_bits - bits;
     if (q > 45) q = 45;
     const double up = ldexp(1.0, q), down = ldexp(1.0, -q);
     int32_t n = 0;

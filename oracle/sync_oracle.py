@@ -54,24 +54,25 @@ def det_exp(x):
     return np.array([f(float(v)) for v in np.atleast_1d(x)])
 
 
-def build_table(sigma_grid, L, K, periodic):
-    """Quantised, image-folded weight table -> (table f64[tlen], q)."""
+def build_table(sigma_grid, L, K, periodic, sum_bits=51):
+    """Quantised, image-folded weight table -> (table f64[tlen], q).  sum_bits = 51: the exact binary64 field; 29: the grid
+    of the library's 32-bit integer field (`fp32` mode)."""
     cap = L + 2
     buf = np.zeros(cap, dtype=np.float64)
     q = C.c_int32(0)
-    n = lib().orc_build_table(C.c_double(float(sigma_grid)), C.c_int32(L), C.c_int32(K),
-                              C.c_int32(int(bool(periodic))), _p(buf), C.c_int32(cap), C.byref(q))
+    n = lib().orc_build_table_bits(C.c_double(float(sigma_grid)), C.c_int32(L), C.c_int32(K),
+                                   C.c_int32(int(bool(periodic))), C.c_int32(int(sum_bits)), _p(buf), C.c_int32(cap), C.byref(q))
     assert n >= 0
     return buf[:n].copy(), int(q.value)
 
 
 class SyncOracle:
-    def __init__(self, par: LatticeGasParams, dt: float, seed: int, ensemble: int = 0, raw_table=None):
+    def __init__(self, par: LatticeGasParams, dt: float, seed: int, ensemble: int = 0, raw_table=None, sum_bits=51):
         self.par = par
         self.dt = float(dt)
         if par.sigma_kernel > 0:
             if raw_table is None:
-                self.table, self.q = build_table(par.sigma_grid, par.L, par.K, par.periodic)
+                self.table, self.q = build_table(par.sigma_grid, par.L, par.K, par.periodic, sum_bits)
             else:                                   # unquantised weights: proves the formula itself
                 self.table, self.q = np.ascontiguousarray(raw_table, dtype=np.float64), None
             mode = 1

@@ -794,3 +794,75 @@ def test_config4_full_size_ensembles(capi):
             check_lattice(big, orc, ensemble=e)
     finally:
         big.close()
+
+
+FP32_CASES = [
+    dict(tag="k1_reflect", L=3000, K=1, sigma=0.01, frac=0.5),
+    dict(tag="k1_periodic", L=1200, K=1, sigma=0.02, periodic=True, frac=0.5),
+    dict(tag="k3_small_box", L=200, K=3, sigma=0.3, frac=0.6),
+    dict(tag="k2_anchors_exit", L=900, K=2, sigma=0.02, frac=0.5, anchor_positions=[0.3, 0.7], anchor_radius=0.05, k_on=3.0, k_off=1.0, k_exit=2.0),
+    dict(tag="table_beyond_lds", L=60000, K=1, sigma=0.1, frac=0.05),
+]
+
+
+@pytest.mark.parametrize("case", FP32_CASES, ids=lambda c: c["tag"])
+def test_fp32_field_is_exact_on_its_own_grid(capi, case):
+    """aps_params.fp32 (BASELINE config 5 asks for float32): weights, W and S are int32 in units of 2^-q with q = 29 - bits
+    of the largest possible sum.  Still integer arithmetic, so the run must equal -- bit for bit, state after every block and
+    the field arrays -- the oracle stepped with the SAME coarse table (oracle/sync_oracle.c with sum_bits = 29), and the field
+    must sit within float32-class distance of the exact (2^-q, q ~ 38) one."""
+    case = dict(case)
+    tag, frac = case.pop("tag"), case.pop("frac")
+    par = params(**case)
+    rng = np.random.default_rng(17)
+    N = max(1, int(frac * par.L * par.K))
+    pos, spin = random_state(rng, par.L, N, par.K)
+    orc = so.SyncOracle(par, dt=0.04, seed=5, sum_bits=29)
+    fine = so.SyncOracle(par, dt=0.04, seed=5)
+    orc.set_state(pos, spin)
+    h = make_handle(capi, par, N, dt=0.04, seed=5, method="tiles", fp32=True)
+    try:
+        tab, q = h.table()
+        assert q == orc.q and q <= 29 and np.array_equal(tab, orc.table) and np.array_equal(tab * 2.0 ** q, np.rint(tab * 2.0 ** q))
+        h.set_state(pos, spin)
+        check_lattice(h, orc)
+        for block in range(4):
+            h.step(25)
+            orc.run(25)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin) and np.array_equal(bd, orc.bound) and np.array_equal(al, orc.alive), (tag, block)
+            check_lattice(h, orc)
+        # distance to the exact field: the same state under the fine table
+        fine.set_state(p, sg, bound=bd, alive=al)
+        _, _, m_fine = fine.field_sites()
+        _, _, m_coarse = orc.field_sites()
+        assert np.max(np.abs(m_fine - m_coarse)) < 2e-4, tag       # float32-class, far above the 2e-11 of the exact grid
+    finally:
+        h.close()
+
+
+def test_fp32_config5_scale_against_oracle_windows(capi):
+    """BASELINE config 5 as it is worded (N = 1e6, float32): the int32 field after 200 steps against the oracle's stencil
+    with the coarse table on wall / transition / interior windows, bit for bit."""
+    L, N = 2_000_000, 1_000_000
+    par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7,
+                                       scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
+    rng = np.random.default_rng(12)
+    pos = rng.choice(L, size=N, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=N)
+    h = make_handle(capi, par, N, dt=0.0125, seed=6, method="tiles", fp32=True)
+    try:
+        tab, q = h.table()
+        otab, oq = so.build_table(par.sigma_grid, L, 1, False, 29)
+        assert q == oq == 12 and np.array_equal(tab, otab[:len(tab)]) and len(tab) == 40001
+        h.set_state(pos, spin)
+        h.step(200)
+        p, s, _, alive = h.get_state()
+        assert alive.all() and (p != pos).mean() > 0.25 and np.bincount(p, minlength=L).max() <= 1
+        W, S, occ = h.get_lattice(0)
+        Rt = len(tab) - 1
+        for a0, b0 in ((0, 700), (Rt - 900, Rt + 900), (L // 2 - 300, L // 2 + 500), (L - Rt - 700, L - Rt + 700), (L - 700, L)):
+            W0, S0 = _oracle_window_field(tab, p.astype(np.int64), s, L, a0, b0)
+            assert np.array_equal(W[a0:b0], W0) and np.array_equal(S[a0:b0], S0), a0
+    finally:
+        h.close()
