@@ -30,7 +30,7 @@ WORK = dict(N=100_000, L=200_000, K=1, xlim=1.0, sigma=0.005, beta=0.7, rate_act
 # other BASELINE configurations, for the record only (never the default bench line): --workload config4 / config5
 EXTRA = {
     "config4": dict(WORK, N=50_000, L=100_000, betas=[3.0 * i / 15 for i in range(16)]),     # 16 beta ensembles, one GPU
-    "config5": dict(WORK, N=1_000_000, L=2_000_000),                                          # f64 here (no f32 path)
+    "config5": dict(WORK, N=1_000_000, L=2_000_000, fp32=True),                               # BASELINE config 5 says float32: the 32-bit field (--f64 for the exact one)
     # not a BASELINE configuration: the same model at a size where the working set (1.5 GB) no longer fits the caches,
     # short-ranged kernel (sigma_g = 10 sites) -- shows the kernels against the HBM roofline they are priced on
     "hbm": dict(WORK, N=16_000_000, L=32_000_000, sigma=10.0 / 32_000_000),
@@ -41,13 +41,13 @@ ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # SURVEY 8d (all-pairs): 4 B state read + 
 #   propose_lattice  N * (4 state + 4 index + 16 {W,S} + 12 occupancy + 1 proposal) + 4 L (site counters cleared)
 #   apply            N * (1 proposal + 4 state + 4 index) + C * (8 state/source word + 8 occupancy) + 4 D + 16 N / 64
 #   field_update     L * 32 ({W,S} read + write) + 4 D
-#   tile_step        L * (32 {W,S} read + write  +  8 K cell words read + write) + 8 D (deposit written, read) + 8 T (counters)
-def step_algo_bytes(kernel, N, L, K, deposits):
+#   tile_step        L * (32 {W,S} read + write [16 with the 32-bit field]  +  8 K cell words read + write) + 8 D (deposit written, read) + 8 T (counters)
+def step_algo_bytes(kernel, N, L, K, deposits, fp32=False):
     changed = 0.6 * deposits          # estimate (a hop makes 2 deposits, a flip or an exit 1); only `apply` uses it
     return {"propose_lattice": 37.0 * N + 4.0 * L,
             "apply": 9.25 * N + 16.0 * changed + 4.0 * deposits,
             "field_update": 32.0 * L + 4.0 * deposits,
-            "tile_step": (32.0 + 8.0 * K) * L + 8.0 * deposits + 8.0 * L / 316.0}.get(kernel, 0.0)
+            "tile_step": ((16.0 if fp32 else 32.0) + 8.0 * K) * L + 8.0 * deposits + 8.0 * L / 316.0}.get(kernel, 0.0)
 
 
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
@@ -78,7 +78,8 @@ def initial_state(w):
 def make_handle(capi, w, device=0, rank=0, world=1, method="auto"):
     return capi.Handle(L=w["L"], K=w["K"], periodic=False, sigma_grid=w["sigma"] / (w["xlim"] / w["L"]),
                        rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"], beta=w.get("betas", [w["beta"]]),
-                       dt=w["dt"], seed=w["seed"], n_particles=w["N"], device=device, rank=rank, world=world, method=method)
+                       dt=w["dt"], seed=w["seed"], n_particles=w["N"], device=device, rank=rank, world=world, method=method,
+                       fp32=bool(w.get("fp32", False)))
 
 
 def cpu_baseline(w, budget_s=12.0):
@@ -280,6 +281,8 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "pde", "gillespie"] + sorted(EXTRA))
     ap.add_argument("--method", default="auto", choices=["auto", "lattice", "pairs", "tiles"])
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K steps; the line reports their median")
+    ap.add_argument("--fp32", action="store_true", help="32-bit integer field (aps_params.fp32); default only for --workload config5")
+    ap.add_argument("--f64", action="store_true", help="force the exact binary64 field")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -293,6 +296,10 @@ def main():
     if args.workload == "gillespie":
         return bench_gillespie(args)
     w = dict(WORK) if args.workload == "config2" else dict(EXTRA[args.workload])
+    if args.fp32:
+        w["fp32"] = True
+    if args.f64:
+        w["fp32"] = False
     n_ens = len(w.get("betas", [0]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -318,7 +325,8 @@ def main():
         wr = dict(w, betas=all_betas[rank * n_ens:(rank + 1) * n_ens])
         h = capi.Handle(L=wr["L"], K=wr["K"], periodic=False, sigma_grid=wr["sigma"] / (wr["xlim"] / wr["L"]),
                         rate_diffusion=wr["rate_diffusion"], rate_active=wr["rate_active"], beta=wr["betas"], dt=wr["dt"],
-                        seed=wr["seed"], n_particles=wr["N"], device=device, ensemble_base=rank * n_ens, method=args.method)
+                        seed=wr["seed"], n_particles=wr["N"], device=device, ensemble_base=rank * n_ens, method=args.method,
+                        fp32=bool(wr.get("fp32", False)))
         for e in range(n_ens):
             h.set_state(pos, spin, ensemble=e)
         h.step(args.warmup)
@@ -526,7 +534,7 @@ def main():
             bracketed = os.environ.get("APS_PROF_BRACKET") is not None
             dep_per_step = deposits / max(n_fu, 1)
             N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
-            algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step) for k in kern}
+            algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32"))) for k in kern}
             dom = max(kern, key=kern.get)
             achieved = algo[dom] / kern[dom] / 1e9
             step_bytes = sum(algo.values())
@@ -562,7 +570,8 @@ def main():
     out = {
         "metric": "particle-steps/sec at N=1e5", "value": w["N"] * n_ens_total * args.steps / elapsed, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "i32 (fixed point 2^-q, the fp32 mode of aps_params)" if w.get("fp32") else "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: N=100000 particles, L=200000 sites, K=1, reflecting walls, "
                                 "sigma=0.005 (4001-tap table), beta=0.7, dt=0.0125, exclusion on") if args.workload == "config2"
                                else f"{'BASELINE ' if args.workload.startswith('config') else ''}{args.workload}: N={w['N']} x {n_ens} ensemble(s), L={w['L']}, K=1, sigma_g={w['sigma'] * w['L']:.0f} sites, dt=0.0125",

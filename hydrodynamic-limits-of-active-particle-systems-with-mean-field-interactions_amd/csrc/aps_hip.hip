@@ -1195,8 +1195,13 @@ __global__ __launch_bounds__(256) void ws_to_double(const int2 *__restrict__ in,
 
 // streaming copy, 16 bytes per lane: the HBM ceiling this box reaches in practice (bench.py quotes it beside the 8 TB/s spec)
 __global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    // four independent 16-byte loads per thread in flight, then the four stores: one workgroup = 16 KB
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * 256; v[u] = i < n ? src[i] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * 256; if (i < n) dst[i] = v[u]; }
 }
 
 // ---- site-centric state <-> particle-indexed arrays (observation, hooks, upload of the tiles method)
@@ -1359,7 +1364,7 @@ struct aps_handle {
     bool fu_table_in_lds = true;
     bool field_dirty = true;
     hipStream_t cap_stream = nullptr;
-    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // captured runs of GRAPH_SIZES[k] steps
+    hipGraphExec_t gexec[2][6] = {};   // [start parity][k]: runs of GRAPH_SIZES[k] steps
     bool graphs_built = false;
     int64_t last_graph_steps = 0, last_single_steps = 0;      // how the last aps_step call was executed
     // tiles formulation (site-centric state, one kernel per step): everything double buffered by step parity
@@ -1761,7 +1766,8 @@ int ts_wbytes(const aps_handle *h) { return h->f32 ? 4 : 8; }
 
 // tile geometry (measured on MI355X, profiles/r02_*): while the whole grid is resident at once (<= 3 workgroups per CU)
 // the frame that gives about 2.4 workgroups per CU is fastest (64 * 5 sites at L = 2e5); larger grids run in waves of
-// workgroups and want the frame with the best work per instruction and three resident workgroups per CU: 256 sites
+// workgroups and want the frame with the best work per instruction at three or four resident workgroups per CU: 256 sites
+// in binary64, 384 (table in LDS) or 320 (table windows) sites with the 32-bit field
 void ts_choose_geometry(aps_handle *h) {
     const int L = h->p.L;
     h->ts_RS = 1;
@@ -1773,7 +1779,7 @@ void ts_choose_geometry(aps_handle *h) {
         if (miss < best) { best = miss; h->ts_RS = rs; }
     }
     if ((double)(((int64_t)L + 507) / 508) * h->E > 3.0 * 256.0)      // even the largest frame leaves more than 3 per CU
-        h->ts_RS = 4;
+        h->ts_RS = !h->f32 ? 4 : (ts_lds_layout(h->tlen, true, 6, 380, h->p.K, 4).total <= 160 * 1024 ? 6 : 5);   // measured: r02 geometry sweeps
     if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
     h->ts_own = 64 * h->ts_RS - 4;
     if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
@@ -2343,40 +2349,44 @@ int aps_commit(aps_handle *h) {
 
 namespace {
 
-constexpr int GRAPH_SIZES[3] = {32, 8, 2};   // steps per captured graph (even: the kernels' parity arguments are baked in)
+constexpr int NGRAPH = 6;
+constexpr int GRAPH_SIZES[NGRAPH] = {32, 16, 8, 4, 2, 1};   // steps per captured graph
 
 // Lattice / tile steps are a few microseconds of GPU time each, less than the host needs to launch their kernels
-// one by one: runs of 32, 8 and 2 steps are captured once (the step index lives in device memory, see stepw) and any
-// step count is replayed as a sum of those.
+// one by one: runs of 32, 16, 8, 4, 2 and 1 steps are captured once -- for either parity of the first step, which the kernels'
+// buffer arguments depend on; the step index itself lives in device memory (stepw) -- and any step count is replayed as
+// a sum of those.
 int build_graphs(aps_handle *h) {
     if (h->graphs_built) return APS_OK;
     if (!h->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-    const bool dirty = h->slots_dirty, pending = h->field_pending;
-    for (int g = 0; g < 3; ++g) {
-        const hipStream_t user_stream = h->stream;
-        const int64_t step0 = h->step;
-        HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        h->stream = h->cap_stream;
-        h->step = 0;                                         // only the parity is baked in: replays start on even steps
-        int rc = APS_OK;
-        for (int k = 0; k < GRAPH_SIZES[g] && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
-        h->stream = user_stream;
-        h->step = step0;
-        hipGraph_t graph = nullptr;
-        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-        const hipError_t ie = hipGraphInstantiate(&h->gexec[g], graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) { h->gexec[g] = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-    }
-    h->slots_dirty = dirty; h->field_pending = pending;      // capturing launched nothing
+    const bool dirty = h->slots_dirty, pending = h->field_pending, stale = h->ws_view_stale;
+    for (int par = 0; par < 2; ++par)
+        for (int g = 0; g < NGRAPH; ++g) {
+            const hipStream_t user_stream = h->stream;
+            const int64_t step0 = h->step;
+            HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            h->stream = h->cap_stream;
+            h->step = par;                                   // only the parity is baked in
+            int rc = APS_OK;
+            for (int k = 0; k < GRAPH_SIZES[g] && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
+            h->stream = user_stream;
+            h->step = step0;
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            const hipError_t ie = hipGraphInstantiate(&h->gexec[par][g], graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { h->gexec[par][g] = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        }
+    h->slots_dirty = dirty; h->field_pending = pending; h->ws_view_stale = stale;      // capturing launched nothing
     h->graphs_built = true;
     return APS_OK;
 }
 
 void drop_graphs(aps_handle *h) {
-    for (int g = 0; g < 3; ++g) if (h->gexec[g]) { (void)hipGraphExecDestroy(h->gexec[g]); h->gexec[g] = nullptr; }
+    for (int par = 0; par < 2; ++par)
+        for (int g = 0; g < NGRAPH; ++g) if (h->gexec[par][g]) { (void)hipGraphExecDestroy(h->gexec[par][g]); h->gexec[par][g] = nullptr; }
     h->graphs_built = false;
 }
 
@@ -2457,12 +2467,11 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     int64_t s = 0;
     static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
     h->last_graph_steps = h->last_single_steps = 0;
-    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps >= GRAPH_SIZES[2]) {
+    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps > 0) {
         if ((rc = build_graphs(h))) return rc;                             // once per handle, on the first stepping call
-        if ((h->step & 1) && nsteps - s > 0) { if ((rc = one_step(h))) return rc; ++s; ++h->last_single_steps; }   // replays start on even steps
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < NGRAPH; ++g)
             for (; nsteps - s >= GRAPH_SIZES[g]; s += GRAPH_SIZES[g]) {
-                HIP_TRY(h, hipGraphLaunch(h->gexec[g], h->stream));
+                HIP_TRY(h, hipGraphLaunch(h->gexec[h->step & 1][g], h->stream));
                 h->step += GRAPH_SIZES[g];
                 h->last_graph_steps += GRAPH_SIZES[g];
                 if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true; }
@@ -2490,7 +2499,7 @@ int aps_copy_bandwidth(aps_handle *h, int64_t nbytes, int32_t reps, double *gbyt
     (void)hipMemsetAsync(a, 1, n16 * 16, h->stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)h->num_cu * 32);
+    const unsigned blocks = (unsigned)((n16 + 1023) / 1024);
     hipLaunchKernelGGL(copy16, dim3(blocks), dim3(256), 0, h->stream, a, b, n16);        // warm-up
     (void)hipEventRecord(e0, h->stream);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16, dim3(blocks), dim3(256), 0, h->stream, a, b, n16);

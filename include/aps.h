@@ -207,7 +207,7 @@ int aps_resort(aps_handle *h);
  * their summed duration, the number of launches and the work done: pair evaluations (PAIRS) or deposits (LATTICE). */
 int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *launches, double *work);
 
-/* How the last aps_step call ran: steps replayed from captured hipGraphs (runs of 32, 8 and 2 steps) and steps launched
+/* How the last aps_step call ran: steps replayed from captured hipGraphs (runs of 32, 16, 8, 4, 2 and 1 steps, for either parity of the first step) and steps launched
  * kernel by kernel. */
 int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps);
 
