@@ -31,7 +31,7 @@ class ParticleSystem:
                  site_capacity=1, crowding_suppresses_rates=False, k_on=0.1, k_off=0.01,
                  suppress_flip_when_bound=True, k_exit=0,
                  # extensions (all optional, after the reference's keywords)
-                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode="sync", method="auto"):
+                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode="sync", method="auto", fp32=False):
         self.L = int(L)
         self.xlim = xlim
         self.K = int(site_capacity)
@@ -94,8 +94,10 @@ class ParticleSystem:
                 f"rates of the other channels from the GPU); mode={mode!r} evaluates the Curie-Weiss rate exp(-beta*sigma*m) "
                 f"on the device and cannot call back into Python")
         if method not in capi.METHODS:
-            raise ValueError("method must be 'auto', 'pairs' (all-pairs kernel) or 'lattice' (incremental lattice field)")
+            raise ValueError("method must be 'auto', 'tiles' (one kernel per step over site tiles), 'lattice' (incremental lattice "
+                             "field, three kernels) or 'pairs' (all-pairs kernel)")
         self.method = method
+        self.fp32 = bool(fp32)                 # 32-bit integer field (aps_params.fp32): float32-class accuracy, still order-independent
         self._handle = None
         self._util = None                      # lazily created handle for compute_local_m_field / step_gillespie
 
@@ -153,7 +155,7 @@ class ParticleSystem:
             dt=self.dt, seed=seed, n_particles=n_particles, minus_anchor=self.minus_anchor,
             immobilize=self.immobilize_when_anchored, suppress_flip=self.suppress_flip_when_bound,
             crowding=self.crowding_suppresses_rates, k_on=self.k_on, k_off=self.k_off, k_exit=self.k_exit,
-            anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site, method=self.method)
+            anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site, method=self.method, fp32=self.fp32)
 
     def _utility_handle(self):
         if self._util is None:

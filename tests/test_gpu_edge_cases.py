@@ -80,3 +80,51 @@ def test_pde_minimal_grid_and_no_tracers():
     gpu.solve()
     assert np.max(np.abs(gpu.rho_p - ref.rho_p)) <= 1e-12 and np.max(np.abs(gpu.rho_m - ref.rho_m)) <= 1e-12
     assert np.all(np.isnan(gpu.v_eff_series)) and len(gpu.snapshots) == ref.nsteps // 7 + 1
+
+
+def test_communicator_argument_and_ordering_errors(capi):
+    """aps_comm_init / aps_step on sharded handles: what must fail does, loudly; a communicator on a one-rank tiles handle
+    changes nothing (the halo exchange has no neighbour); the step-by-step path (no hipGraph: handles with a communicator)
+    equals graph replay and propose / commit driven by hand."""
+    import ctypes as C
+    pytest.importorskip("torch")                          # as in production: torch's librccl is the process's RCCL
+    par = LatticeGasParams.from_kwargs(L=4000, xlim=1.0, rate_diffusion=0.5, rate_active=4.0, beta=1.0, scale_rates=False,
+                                       local_kernel_sigma=0.003, site_capacity=1)
+    rng = np.random.default_rng(8)
+    pos = rng.choice(4000, size=1800, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=1800)
+    kw = dict(L=par.L, K=1, periodic=False, sigma_grid=par.sigma_grid, rate_diffusion=0.5, rate_active=4.0, beta=[1.0], dt=0.03, seed=2,
+              n_particles=1800)
+    a, b, c = capi.Handle(method="tiles", **kw), capi.Handle(method="tiles", **kw), capi.Handle(method="tiles", **kw)
+    sharded = capi.Handle(method="tiles", rank=1, world=2, **kw)
+    try:
+        lib = capi.load()
+        assert lib.aps_comm_init(a._h, None) == capi.APS_ERR_ARG                  # null id
+        assert lib.aps_comm_init(None, C.cast((C.c_uint8 * 128)(), C.c_void_p)) == capi.APS_ERR_ARG
+        n = C.c_int32()
+        assert lib.aps_comm_ranks(a._h, C.byref(n)) == capi.APS_ERR_STATE         # no communicator yet
+        for h in (a, b, c, sharded):
+            h.set_state(pos, spin)
+        with pytest.raises(capi.ApsError, match="communicator"):
+            sharded.step(1)                                                       # sharded handle, no communicator, no hand-driven halo
+        with pytest.raises(capi.ApsError):
+            sharded.halo_from(a)                                                  # not a neighbour rank of that shape
+        with pytest.raises(capi.ApsError):
+            a.halo_pack(0)                                                        # not a sharded handle
+        a.comm_init(capi.comm_unique_id())
+        assert a.comm_ranks() == 1
+        with pytest.raises(capi.ApsError, match="already"):
+            a.comm_init(capi.comm_unique_id())
+        a.step(37)                                                                # step by step (a communicator disables nothing else)
+        b.step(37)                                                                # hipGraph replay: 32 + 4 + 1
+        assert b.step_info() == (37, 0)
+        for _ in range(37):
+            c.propose()
+            c.commit()
+        for x, y, z in zip(a.get_state(), b.get_state(), c.get_state()):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        for x, y in zip(a.get_lattice(), b.get_lattice()):
+            assert np.array_equal(x, y)
+    finally:
+        for h in (a, b, c, sharded):
+            h.close()
