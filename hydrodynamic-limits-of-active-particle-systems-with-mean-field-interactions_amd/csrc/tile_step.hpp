@@ -65,7 +65,7 @@ __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, i
     l.occ = l.props + (TS * K + 7) / 8 * 8;
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
     l.plist = l.misc + 64;
-    l.tab = (l.plist + (l.cells_in_regs ? (size_t)FU_WAVES * l.Q * 8 : 0) + 15) / 16 * 16;
+    l.tab = (l.plist + (l.cells_in_regs ? TS * (size_t)K * 8 : 0) + 15) / 16 * 16;
     const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes;
     const size_t red = (size_t)FU_WAVES * TS * 2 * wbytes;
     l.field = l.tab + red;                                      // fresh {W, S} of the frame sites, behind the partial sums
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     double2 *fieldL = reinterpret_cast<double2 *>(lds_c + lay.field);        // [TS]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
     uint32_t *segP = seg_all + wave * 4 * (SEG + 4), *segM = segP + SEG + 4, *segF = segM + SEG + 4, *segI = segF + SEG + 4;
-    uint2 *plist = reinterpret_cast<uint2 *>(lds_c + lay.plist) + (size_t)wave * lay.Q;   // this wave's particles {pos | k << 16, cell}
+    uint2 *plist = reinterpret_cast<uint2 *>(lds_c + lay.plist);   // the frame's particles {pos | k << 16, cell}, pooled over the four waves
     const int tile = a.tile_lo + (int)blockIdx.x;
     const int own0 = tile * OWN, own_n = min(OWN, L - own0), nfr = own_n + 4;   // owned sites, valid frame positions
     const int x0 = own0 - 2;                                   // site of frame position 0 (may lie outside the lattice)
@@ -215,6 +215,8 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         typedef __attribute__((address_space(3))) W lds_w;
         tbase = (uint32_t)(size_t)(lds_w *)tab;               // LDS byte offset of the table (or of the windows)
     }
+    if (t < 16) misc[t] = 0;                                   // counters used before the first data barrier (particle list)
+    __syncthreads();
 #ifdef APS_STAMPS
     unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_part = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long f_start = t0, r_start = __builtin_amdgcn_s_memrealtime();
@@ -316,24 +318,20 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     if (!a.field_mode) {
         for (int i = t; i < a.ntile; i += FU_THREADS) { gS += a.gpart_in[((size_t)e * a.ntile + i) * 2]; gN += a.gpart_in[((size_t)e * a.ntile + i) * 2 + 1]; }
     }
-    if (t < 16) misc[t] = 0;
     for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;   // EV_NONE everywhere
-    // this wave's particles and their random numbers
-    int n_w = 0;
-    uint2 mine = make_uint2(0u, CELL_EMPTY);
-    uint32_t rx[4] = {0u, 0u, 0u, 0u};
+    // the frame's particles: every wave appends the occupied cells of its chunk to ONE list (an LDS atomic per wave and
+    // round), so that afterwards the proposals run a lane per particle over full wavefronts
     if (regs) {
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             if (cpk[u] == -2) creg[u] = CELL_EMPTY;
             const bool occ = creg[u] != CELL_EMPTY && cpk[u] >= 0;
             const unsigned long long mm = __ballot(occ);
-            if (occ) plist[n_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)cpk[u], creg[u]);
-            n_w += __popcll(mm);
-        }
-        if (!a.field_only && lane < n_w) {
-            mine = plist[lane];
-            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, rx);
+            const int cnt_u = __popcll(mm);
+            int base = 0;
+            if (lane == 0 && cnt_u) base = atomicAdd(&misc[3], cnt_u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (occ) plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)cpk[u], creg[u]);
         }
 #pragma unroll
         for (int u = 0; u < NR; ++u) { const int c = c_lo + lane + 64 * u; if (c < c_hi) cellL[c] = creg[u]; }
@@ -348,7 +346,14 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         x8[r] = ((uint32_t)s + TS_BIAS) << SH; accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0;
     }
     if (TAB_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's table chunks have landed
-    __syncthreads();                                           // table and cells staged
+    __syncthreads();                                           // table, cells and the particle list staged
+    const int n_part = regs ? misc[3] : 0;
+    uint2 mine = make_uint2(0u, CELL_EMPTY);
+    uint32_t rx[4] = {0u, 0u, 0u, 0u};
+    if (!a.field_only && t < n_part) {                         // this thread's particle: its random numbers now, ahead of the sweep
+        mine = plist[t];
+        philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, rx);
+    }
     TSTAMP(f_stage)
     // ---------------------------------------------------------------- 1  deposits of the previous step -> W, S of the frame
     const bool windowed = !TAB_LDS && BC == 0 && !wall;
@@ -583,8 +588,8 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                                                  occL[pos + 1], occL[pos], occL[pos + 2], x);
         };
         if (regs) {
-            if (lane < n_w) propose_one(mine, rx);
-            for (int j = 64 + lane; j < n_w; j += 64) {        // more than 64 particles in this wave's chunk (dense or K > 1)
+            if (t < n_part) propose_one(mine, rx);
+            for (int j = FU_THREADS + t; j < n_part; j += FU_THREADS) {   // more than 256 particles on the frame (K > 1)
                 const uint2 pc = plist[j];
                 uint32_t x[4];
                 philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
