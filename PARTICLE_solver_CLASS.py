@@ -1,5 +1,10 @@
 """Drop-in module name of the reference: `from PARTICLE_solver_CLASS import ParticleSystem`
-(PARTICLE_solver_BIOLOGY_EXCLUSION*.py line 12/13).  Re-exports the MI355X-backed class."""
+(PARTICLE_solver_BIOLOGY_EXCLUSION*.py line 12/13).  Re-exports the MI355X-backed class.
+
+Same constructor keywords, attributes and `run()` result dictionary as the reference.  What differs when a driver is left
+unchanged: `run()` advances in fixed steps `dt` (synchronous scheme, first order in dt against the reference's exact
+Gillespie dynamics; `mode="gillespie_gpu"` or `mode="gillespie"` give the exact dynamics), `m_local_list[k]` is the field of
+the observed state, a custom `flip_rate_fn` needs `mode="gillespie"`, K <= 32 and L <= 2^25."""
 import importlib
 import os
 import sys

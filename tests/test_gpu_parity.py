@@ -317,8 +317,9 @@ def test_full_size_properties(capi, method):
         b.close()
 
 
-def test_config2_ten_thousand_steps_field_stays_exact(capi):
-    """BASELINE config 2 at its full length (N = 1e5, 10 000 steps, lattice formulation): after 10 000 incremental updates the
+@pytest.mark.parametrize("method", ["lattice", "tiles"])
+def test_config2_ten_thousand_steps_field_stays_exact(capi, method):
+    """BASELINE config 2 at its full length (N = 1e5, 10 000 steps, both incremental lattice formulations): after 10 000 incremental updates the
     smoothed histograms W, S on all 2e5 sites still equal a from-scratch recomputation from the final state bit for bit
     (no drift: every value sits on the weight grid), the run is independent of how it is cut into calls (one call = 312
     graph replays + a tail; 16 calls of 625 steps), exclusion holds and nobody is lost."""
@@ -328,8 +329,8 @@ def test_config2_ten_thousand_steps_field_stays_exact(capi):
     rng = np.random.default_rng(5)
     pos = rng.choice(L, size=N, replace=False).astype(np.int32)
     spin = rng.choice(np.array([1, -1], np.int8), size=N)
-    a = make_handle(capi, par, N, dt=0.0125, seed=3, method="lattice")
-    b = make_handle(capi, par, N, dt=0.0125, seed=3, method="lattice")
+    a = make_handle(capi, par, N, dt=0.0125, seed=3, method=method)
+    b = make_handle(capi, par, N, dt=0.0125, seed=3, method=method)
     try:
         a.set_state(pos, spin)
         b.set_state(pos, spin)
