@@ -46,6 +46,8 @@ struct PdeArgs {
     const double *twc, *tws;            // [L] cos / sin(2 pi j / L)
     double *rho_p, *rho_m, *m_series, *var_series, *v_eff, *D_eff, *snapshots, *m_snapshots, *fft_re, *fft_im, *tracer_x;
     int8_t *tracer_s;
+    double *work;                       // systems beyond LDS: [n_systems][work_stride] fields + kernel taps in global memory (else null)
+    long long work_stride;
     double *hist;                       // [n_systems][window][n_tracers] ring of unwrapped tracer positions
     double *trx; int8_t *trs;           // [n_systems][n_tracers] working tracer state
 };
@@ -133,9 +135,13 @@ __device__ inline void diffuse2(const PdeArgs &a, double *dp, double *dm, double
 __global__ __launch_bounds__(NT) void pde_kernel(const PdeArgs a) {
     extern __shared__ double lds[];
     const int L = a.p.L, t = threadIdx.x, sys = blockIdx.x, ntr = a.p.n_tracers, nsteps = a.p.nsteps;
-    double *rp = lds, *rm = rp + L, *xp = rm + L, *xm = xp + L, *mf = xm + L, *ktab = mf + L;
-    double *red = ktab + ((a.ktaps + 2) & ~1);
-    double4 *scan = reinterpret_cast<double4 *>(lds + ((5 * L + ((a.ktaps + 2) & ~1) + NT + 3) & ~3));   // 32-byte aligned
+    // the five fields and the kernel taps: in LDS when they fit (L <= ~3000), else in this system's slab of global memory
+    // (one workgroup = one CU: its L1 / the L2 serve it, workgroup barriers order the accesses); the scan scratch stays in LDS
+    double *fields = a.work ? a.work + (size_t)sys * (size_t)a.work_stride : lds;
+    double *rp = fields, *rm = rp + L, *xp = rm + L, *xm = xp + L, *mf = xm + L, *ktab = mf + L;
+    double *red = a.work ? lds : ktab + ((a.ktaps + 2) & ~1);
+    double4 *scan = a.work ? reinterpret_cast<double4 *>(lds + ((NT + 3) & ~3))
+                           : reinterpret_cast<double4 *>(lds + ((5 * L + ((a.ktaps + 2) & ~1) + NT + 3) & ~3));   // 32-byte aligned
     const double beta = a.beta[sys], dx = a.dx, dt = a.p.dt, lam = a.p.lam;
     for (int i = t; i < L; i += NT) { rp[i] = a.rho_p0[(size_t)sys * L + i]; rm[i] = a.rho_m0[(size_t)sys * L + i]; }
     for (int i = t; i <= a.ktaps; i += NT) ktab[i] = a.ktab[i];
@@ -414,8 +420,13 @@ int pde_solve_batch(const pde_params *p, int32_t n_systems, const double *beta, 
     OUT(tracer_x, tracer_x, ST); OUT(tracer_s, tracer_s, ST);
 #undef UP
 #undef OUT
-    const size_t lds = (size_t)((5 * L + ((ktaps + 2) & ~1) + NT + 3) & ~3) * sizeof(double) + (size_t)2 * NT * sizeof(double4);
-    if (lds > 160 * 1024) return bad("system does not fit the 160 KB of LDS");
+    size_t lds = (size_t)((5 * L + ((ktaps + 2) & ~1) + NT + 3) & ~3) * sizeof(double) + (size_t)2 * NT * sizeof(double4);
+    if (lds > 160 * 1024) {                                    // beyond LDS: the fields live in global memory, the scans' scratch in LDS
+        a.work_stride = (long long)((5 * (size_t)L + ((ktaps + 2) & ~1) + 3) & ~(size_t)3);
+        a.work = d.alloc<double>((size_t)n_systems * (size_t)a.work_stride);
+        if (!a.work) { g_err = "pde_solve_batch: device allocation failed (work)"; return PDE_ERR_HIP; }
+        lds = (size_t)((NT + 3) & ~3) * sizeof(double) + (size_t)2 * NT * sizeof(double4);
+    }
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&pde_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         g_err = "pde_solve_batch: cannot raise the dynamic LDS limit"; return PDE_ERR_HIP;
     }

@@ -29,7 +29,7 @@ class PdeParams(C.Structure):
                 ("kernel_sigma", C.c_double), ("seed", C.c_uint64)]
 
 
-PDE_MAX_L = 3072
+PDE_MAX_L = 1 << 22          # fields in LDS up to L ~ 3000 (PDE_LDS_L of include/pde.h), in global memory beyond
 
 
 def _lib():
@@ -116,7 +116,7 @@ class IMEXPDE:
         self.outdir = outdir                                       # kept as an attribute; nothing is written
         self.device, self.record_fft = int(device), bool(record_fft)
         if L > PDE_MAX_L:
-            raise ValueError(f"L <= {PDE_MAX_L}: one system lives in one workgroup's LDS")
+            raise ValueError(f"L <= {PDE_MAX_L}")
         if seed is not None:
             np.random.seed(seed)                                   # ref :55-56
         self.rho_mean = 1.0 / self.xlim

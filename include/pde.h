@@ -21,7 +21,8 @@ extern "C" {
 #define PDE_ERR_HIP (-2)
 #define PDE_ERR_NODEVICE (-4)
 
-#define PDE_MAX_L 3072          /* one system lives in one workgroup's LDS */
+#define PDE_MAX_L (1 << 22)     /* one workgroup per system; its fields sit in LDS up to L ~ 3000, in global memory beyond */
+#define PDE_LDS_L 3072           /* largest L whose fields fit one workgroup's LDS (plain local kernel) */
 
 /* Mirrors the reference constructor keywords (ref :13-61). */
 typedef struct pde_params {

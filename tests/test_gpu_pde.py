@@ -72,6 +72,25 @@ def test_gpu_pde_matches_oracle_with_the_same_random_numbers(pde, case, L):
     close(got["D_eff_series"], want["D_eff_series"], 1e-9, "D_eff")
 
 
+@pytest.mark.parametrize("case", [CASES[1], CASES[0]], ids=lambda c: c["tag"])
+def test_gpu_pde_beyond_lds_matches_oracle(pde, case):
+    """L = 6000: five fields of 6000 doubles no longer fit one workgroup's LDS; they then live in the system's slab of global
+    memory (same kernel, same arithmetic).  Same bars against the oracle with the same random numbers."""
+    kw = dict(L=6000, xlim=1.0, T=0.03, dt=5e-4, gamma=2.33e-4, lam=0.6, beta=2.0, kernel_sigma=0.004, snapshot_interval=20)
+    args = dict(bc=case["bc"], active_model=case["active_model"], gaussian_kernel=case["gaussian_kernel"], seed=99, **kw)
+    orc = PdeOracle(**args)
+    orc.initialize(mode=case["init"], rho0=1.0, noise=0.2, n_tracers=100)
+    gpu = pde.IMEXPDE(**args)
+    gpu.initialize(mode=case["init"], rho0=1.0, noise=0.2, n_tracers=100)
+    orc.solve(record_randoms=True)
+    gpu.solve(rand_u=np.array(orc.rand_u), rand_n=np.array(orc.rand_n))
+    want, got = orc.get_output(), gpu.get_output()
+    for k in ("rho_p", "rho_m", "m_series", "var_series", "snapshots", "m_snapshots"):
+        close(got[k], want[k], 1e-11, (case["tag"], k))
+    assert np.array_equal(gpu.tracer_state, orc.tracer_state)
+    close(gpu.tracers_unwrapped, orc.tracers_unwrapped, 1e-9, "tracers")
+
+
 def test_gpu_pde_matches_reference_fixture_fields(pde, golden):
     """Fields against the reference's own runs (fixture G6): the densities do not depend on the tracer noise."""
     g = golden("g6_pde.npz")
@@ -120,7 +139,7 @@ def test_batched_betas_equal_single_runs_and_tracers_follow_theory(pde):
 
 def test_pde_error_paths(pde):
     with pytest.raises(ValueError):
-        pde.IMEXPDE(L=5000)
+        pde.IMEXPDE(L=(1 << 22) + 1)
     s = pde.IMEXPDE(L=64, T=0.01, bc="dirichlet")
     s.initialize(n_tracers=8)
     with pytest.raises(ValueError):
