@@ -1193,6 +1193,22 @@ __global__ __launch_bounds__(256) void ws_to_double(const int2 *__restrict__ in,
     if (i < n) { const int2 v = in[i]; out[i] = make_double2((double)v.x * down, (double)v.y * down); }
 }
 
+// halo of a site-sharded tiles handle: its segments (ranges of the cell / ws / dcnt / dep arrays) <-> ONE packed message per
+// neighbour.  Every transport (ncclSend / ncclRecv, device copy between two handles, host bytes) moves packed messages
+// that this one kernel packs and unpacks.  All segment sizes are multiples of 4 bytes.
+struct HaloSegD { unsigned long long arr_off, msg_off; unsigned bytes; int array; };
+constexpr int HALO_BPS = 32;                 // workgroups per segment
+__global__ __launch_bounds__(256) void halo_move(const HaloSegD *__restrict__ segs, char *a0, char *a1, char *a2, char *a3, char *msg, int unpack) {
+    const HaloSegD g = segs[blockIdx.x / HALO_BPS];
+    char *arr = (g.array == 0 ? a0 : g.array == 1 ? a1 : g.array == 2 ? a2 : a3) + g.arr_off;
+    char *m = msg + g.msg_off;
+    const unsigned words = g.bytes >> 2;
+    for (unsigned i = (blockIdx.x % HALO_BPS) * 256 + threadIdx.x; i < words; i += HALO_BPS * 256) {
+        if (unpack) reinterpret_cast<uint32_t *>(arr)[i] = reinterpret_cast<const uint32_t *>(m)[i];
+        else reinterpret_cast<uint32_t *>(m)[i] = reinterpret_cast<const uint32_t *>(arr)[i];
+    }
+}
+
 // streaming copy, 16 bytes per lane: the HBM ceiling this box reaches in practice (bench.py quotes it beside the 8 TB/s spec)
 __global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
     // four independent 16-byte loads per thread in flight, then the four stores: one workgroup = 16 KB
@@ -1379,6 +1395,12 @@ struct aps_handle {
     int2 *d_wsi[2] = {nullptr, nullptr};
     // site-range sharding of the tiles formulation: this rank steps tiles [ts_lo, ts_hi) = sites [own_lo, own_hi)
     int ts_lo = 0, ts_hi = 0, own_lo = 0, own_hi = 0, ts_reach = 0;
+    // packed halo messages: [0] this rank's first block (for the left neighbour) / the block received from the RIGHT neighbour
+    // (its first block); [1] this rank's last block / the block received from the LEFT neighbour (its last block)
+    char *d_halo_send[2] = {nullptr, nullptr}, *d_halo_recv[2] = {nullptr, nullptr};
+    HaloSegD *d_halo_seg_send[2] = {nullptr, nullptr}, *d_halo_seg_recv[2] = {nullptr, nullptr};
+    int halo_nseg_send[2] = {0, 0}, halo_nseg_recv[2] = {0, 0};
+    size_t halo_bytes_send[2] = {0, 0}, halo_bytes_recv[2] = {0, 0};
     int ts_RS = 2, ts_own = 124, ts_ntile = 0, ts_dcap = 0;
     bool ts_table_in_lds = true;
     bool slots_dirty = false;                  // the particle-indexed arrays lag behind the cells
@@ -1886,27 +1908,70 @@ void halo_peers(const aps_handle *h, int &left, int &right) {
     else { if (right >= h->world) right = -1; }
 }
 
-// after the tile kernel of a step: send this rank's boundary data of the freshly written buffers, receive the neighbours'
-int halo_exchange_rccl(aps_handle *h) {
-    const int buf = (int)((h->step & 1) ^ 1);
-    int left, right;
+// segment tables of the four blocks this rank packs / unpacks, on the device (built once: they do not depend on the step)
+int halo_setup(aps_handle *h) {
+    int left, right, lo, hi;
     halo_peers(h, left, right);
-    std::vector<HaloSeg> sf, sl, rr, rl;
-    int lo, hi;
-    halo_segments(h, h->ts_lo, h->ts_hi, 0, sf);                       // my first block -> left neighbour
-    halo_segments(h, h->ts_lo, h->ts_hi, 1, sl);                       // my last block  -> right neighbour
-    if (right >= 0) { rank_tiles(h, right, lo, hi); halo_segments(h, lo, hi, 0, rr); }   // the right neighbour's first block
-    if (left >= 0) { rank_tiles(h, left, lo, hi); halo_segments(h, lo, hi, 1, rl); }     // the left neighbour's last block
+    for (int side = 0; side < 2; ++side) {
+        for (int recv = 0; recv < 2; ++recv) {
+            std::vector<HaloSeg> segs;
+            if (!recv) halo_segments(h, h->ts_lo, h->ts_hi, side, segs);
+            else {
+                const int peer = side == 0 ? right : left;       // recv[0]: the right neighbour's first block, recv[1]: the left one's last
+                if (peer < 0) continue;
+                rank_tiles(h, peer, lo, hi);
+                halo_segments(h, lo, hi, side, segs);
+            }
+            std::vector<HaloSegD> tab;
+            size_t off = 0;
+            for (const HaloSeg &g : segs) {
+                if (!g.bytes) continue;
+                tab.push_back({(unsigned long long)g.off, (unsigned long long)off, (unsigned)g.bytes, g.array});
+                off += (g.bytes + 15) / 16 * 16;
+            }
+            HaloSegD **dseg = recv ? &h->d_halo_seg_recv[side] : &h->d_halo_seg_send[side];
+            char **dmsg = recv ? &h->d_halo_recv[side] : &h->d_halo_send[side];
+            (recv ? h->halo_nseg_recv[side] : h->halo_nseg_send[side]) = (int)tab.size();
+            (recv ? h->halo_bytes_recv[side] : h->halo_bytes_send[side]) = off;
+            int rc;
+            if ((rc = dev_alloc(h, dseg, tab.size())) || (rc = dev_alloc(h, dmsg, off))) return rc;
+            HIP_TRY(h, hipMemcpyAsync(*dseg, tab.data(), tab.size() * sizeof(HaloSegD), hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+// pack this rank's block `side` of the freshly written buffers into its message / unpack a received message
+int halo_launch(aps_handle *h, int side, bool unpack) {
+    const int buf = (int)((h->step & 1) ^ 1);
+    const int nseg = unpack ? h->halo_nseg_recv[side] : h->halo_nseg_send[side];
+    if (!nseg) return APS_OK;
+    hipLaunchKernelGGL(halo_move, dim3((unsigned)(nseg * HALO_BPS)), dim3(256), 0, h->stream,
+                       unpack ? h->d_halo_seg_recv[side] : h->d_halo_seg_send[side], halo_array(h, 0, buf), halo_array(h, 1, buf),
+                       halo_array(h, 2, buf), halo_array(h, 3, buf), unpack ? h->d_halo_recv[side] : h->d_halo_send[side], unpack ? 1 : 0);
+    HIP_TRY(h, hipGetLastError());
+    return APS_OK;
+}
+
+// after the tile kernel of a step: one packed message to each neighbour rank, one from each (ncclSend / ncclRecv in one group)
+int halo_exchange_rccl(aps_handle *h) {
+    int left, right, rc;
+    halo_peers(h, left, right);
+    if (left >= 0 && (rc = halo_launch(h, 0, false))) return rc;
+    if (right >= 0 && (rc = halo_launch(h, 1, false))) return rc;
     ncclResult_t nr = g_rccl.GroupStart();
     // order per pair of ranks (matters when left and right are the same rank): sends first-block then last-block,
     // receives the peer's first-block (it is my right neighbour's) then its last-block
-    if (nr == ncclSuccess && left >= 0) for (const HaloSeg &g : sf) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Send(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, left, h->comm, h->stream);
-    if (nr == ncclSuccess && right >= 0) for (const HaloSeg &g : sl) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Send(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, right, h->comm, h->stream);
-    if (nr == ncclSuccess && right >= 0) for (const HaloSeg &g : rr) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Recv(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, right, h->comm, h->stream);
-    if (nr == ncclSuccess && left >= 0) for (const HaloSeg &g : rl) if (g.bytes && nr == ncclSuccess) nr = g_rccl.Recv(halo_array(h, g.array, buf) + g.off, g.bytes, ncclUint8, left, h->comm, h->stream);
+    if (nr == ncclSuccess && left >= 0 && h->halo_bytes_send[0]) nr = g_rccl.Send(h->d_halo_send[0], h->halo_bytes_send[0], ncclUint8, left, h->comm, h->stream);
+    if (nr == ncclSuccess && right >= 0 && h->halo_bytes_send[1]) nr = g_rccl.Send(h->d_halo_send[1], h->halo_bytes_send[1], ncclUint8, right, h->comm, h->stream);
+    if (nr == ncclSuccess && right >= 0 && h->halo_bytes_recv[0]) nr = g_rccl.Recv(h->d_halo_recv[0], h->halo_bytes_recv[0], ncclUint8, right, h->comm, h->stream);
+    if (nr == ncclSuccess && left >= 0 && h->halo_bytes_recv[1]) nr = g_rccl.Recv(h->d_halo_recv[1], h->halo_bytes_recv[1], ncclUint8, left, h->comm, h->stream);
     const ncclResult_t ge = g_rccl.GroupEnd();
     if (nr == ncclSuccess) nr = ge;
     if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("halo exchange (ncclSend/ncclRecv): ") + g_rccl.GetErrorString(nr));
+    if (right >= 0 && (rc = halo_launch(h, 0, true))) return rc;
+    if (left >= 0 && (rc = halo_launch(h, 1, true))) return rc;
     return APS_OK;
 }
 
@@ -2195,6 +2260,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
             if (hipMemcpyAsync(h->d_table_i, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "integer table upload failed"; return die(APS_ERR_HIP); }
         }
+        if (h->world > 1 && (rc = halo_setup(h))) return die(rc);
         const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K, ts_wbytes(h)).total;
         if (need > 160 * 1024) { h->err = "tiles: site capacity too large for the tile kernel's LDS staging"; return die(APS_ERR_ARG); }
         if (need > 48 * 1024 &&
@@ -2224,7 +2290,9 @@ void aps_destroy(aps_handle *h) {
     if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
     for (int b = 0; b < 2; ++b)
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
-    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)h->d_wsi[1]}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)h->d_wsi[1],
+                    (void *)h->d_halo_send[0], (void *)h->d_halo_send[1], (void *)h->d_halo_recv[0], (void *)h->d_halo_recv[1], (void *)h->d_halo_seg_send[0],
+                    (void *)h->d_halo_seg_send[1], (void *)h->d_halo_seg_recv[0], (void *)h->d_halo_seg_recv[1]}) if (q) (void)hipFree(q);
     for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_lo_hi, (void *)h->d_ref_ok, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);
     void *ptrs[] = {h->d_src, h->d_orig, h->d_pcnt, h->d_plist, h->d_prop_own, h->d_anchor, h->d_sp8, h->d_tinfo,
                     h->d_stamps, h->d_plan, h->d_plan_n, h->d_accW, h->d_accS, h->d_occ, h->d_table, h->d_beta, h->d_exit, h->d_S, h->d_W, h->d_mfield, h->d_occ4, h->d_gsum,
@@ -2789,37 +2857,32 @@ int aps_halo_copy(aps_handle *dst, aps_handle *src) {
     int left, right;
     halo_peers(dst, left, right);
     if (src->rank != left && src->rank != right) return fail(h, APS_ERR_ARG, "aps_halo_copy: src is not a neighbour rank of dst");
-    HIP_TRY(h, hipStreamSynchronize(src->stream));
     // both handles have launched this step's kernel and not yet committed: the fresh buffers are [(step & 1) ^ 1] on either side
     if ((dst->step & 1) != (src->step & 1)) return fail(h, APS_ERR_STATE, "aps_halo_copy: the two handles are at different steps");
-    const int buf = (int)((dst->step & 1) ^ 1);
-    std::vector<HaloSeg> segs;
-    if (src->rank == right) halo_segments(src, src->ts_lo, src->ts_hi, 0, segs);     // the right neighbour's first block
-    if (src->rank == left) halo_segments(src, src->ts_lo, src->ts_hi, 1, segs);      // the left neighbour's last block
-    for (const HaloSeg &g : segs)
-        if (g.bytes) HIP_TRY(h, hipMemcpyAsync(halo_array(dst, g.array, buf) + g.off, halo_array(src, g.array, buf) + g.off, g.bytes, hipMemcpyDeviceToDevice, dst->stream));
+    int rc;
+    for (int side = 0; side < 2; ++side) {                       // side 0: src's first block (src is dst's right neighbour), 1: its last
+        if (src->rank != (side == 0 ? right : left)) continue;
+        if (src->halo_bytes_send[side] != dst->halo_bytes_recv[side]) return fail(h, APS_ERR_STATE, "aps_halo_copy: block sizes differ");
+        if ((rc = halo_launch(src, side, false))) { h->err = src->err; return rc; }
+        HIP_TRY(h, hipStreamSynchronize(src->stream));
+        HIP_TRY(h, hipMemcpyAsync(dst->d_halo_recv[side], src->d_halo_send[side], src->halo_bytes_send[side], hipMemcpyDeviceToDevice, dst->stream));
+        if ((rc = halo_launch(dst, side, true))) return rc;
+    }
     HIP_TRY(h, hipStreamSynchronize(dst->stream));
     return APS_OK;
 }
 
-// transport-agnostic halo: this rank's first (side 0) or last (side 1) block as bytes in a host buffer, and the reverse for
-// a block received from a neighbour (from_side 0: the RIGHT neighbour's first block, 1: the LEFT neighbour's last block)
+// transport-agnostic halo: this rank's first (side 0) or last (side 1) block as one packed message in a host buffer, and
+// the reverse for a message received from a neighbour (from_side 0: the RIGHT neighbour's first block, 1: the LEFT one's last)
 int aps_halo_pack(aps_handle *h, int32_t side, uint8_t *host, int64_t cap, int64_t *nbytes) {
     if (!h || !nbytes || side < 0 || side > 1) return APS_ERR_ARG;
     if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_pack: not a site-sharded tiles handle");
-    std::vector<HaloSeg> segs;
-    halo_segments(h, h->ts_lo, h->ts_hi, side, segs);
-    int64_t total = 0;
-    for (const HaloSeg &g : segs) total += (int64_t)g.bytes;
-    *nbytes = total;
+    *nbytes = (int64_t)h->halo_bytes_send[side];
     if (!host) return APS_OK;
-    if (cap < total) return fail(h, APS_ERR_ARG, "aps_halo_pack: buffer too small");
-    const int buf = (int)((h->step & 1) ^ 1);
-    int64_t off = 0;
-    for (const HaloSeg &g : segs) {
-        if (g.bytes) HIP_TRY(h, hipMemcpyAsync(host + off, halo_array(h, g.array, buf) + g.off, g.bytes, hipMemcpyDeviceToHost, h->stream));
-        off += (int64_t)g.bytes;
-    }
+    if (cap < *nbytes) return fail(h, APS_ERR_ARG, "aps_halo_pack: buffer too small");
+    int rc = halo_launch(h, side, false);
+    if (rc) return rc;
+    if (*nbytes) HIP_TRY(h, hipMemcpyAsync(host, h->d_halo_send[side], (size_t)*nbytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
 }
@@ -2827,22 +2890,11 @@ int aps_halo_pack(aps_handle *h, int32_t side, uint8_t *host, int64_t cap, int64
 int aps_halo_unpack(aps_handle *h, int32_t from_side, const uint8_t *host, int64_t nbytes) {
     if (!h || !host || from_side < 0 || from_side > 1) return APS_ERR_ARG;
     if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_unpack: not a site-sharded tiles handle");
-    int left, right, lo, hi;
-    halo_peers(h, left, right);
-    const int peer = from_side == 0 ? right : left;
-    if (peer < 0) return fail(h, APS_ERR_ARG, "aps_halo_unpack: no neighbour on that side (reflecting wall)");
-    rank_tiles(h, peer, lo, hi);
-    std::vector<HaloSeg> segs;
-    halo_segments(h, lo, hi, from_side, segs);
-    int64_t total = 0;
-    for (const HaloSeg &g : segs) total += (int64_t)g.bytes;
-    if (total != nbytes) return fail(h, APS_ERR_ARG, "aps_halo_unpack: byte count does not match the neighbour's block");
-    const int buf = (int)((h->step & 1) ^ 1);
-    int64_t off = 0;
-    for (const HaloSeg &g : segs) {
-        if (g.bytes) HIP_TRY(h, hipMemcpyAsync(halo_array(h, g.array, buf) + g.off, host + off, g.bytes, hipMemcpyHostToDevice, h->stream));
-        off += (int64_t)g.bytes;
-    }
+    if (!h->halo_nseg_recv[from_side]) return fail(h, APS_ERR_ARG, "aps_halo_unpack: no neighbour on that side (reflecting wall)");
+    if ((int64_t)h->halo_bytes_recv[from_side] != nbytes) return fail(h, APS_ERR_ARG, "aps_halo_unpack: byte count does not match the neighbour's block");
+    HIP_TRY(h, hipMemcpyAsync(h->d_halo_recv[from_side], host, (size_t)nbytes, hipMemcpyHostToDevice, h->stream));
+    int rc = halo_launch(h, from_side, true);
+    if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return APS_OK;
 }
