@@ -1381,6 +1381,7 @@ struct aps_handle {
     bool field_dirty = true;
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec[2][6] = {};   // [start parity][k]: runs of GRAPH_SIZES[k] steps
+    hipGraphExec_t gexact[2][65] = {}; // [start parity][n]: a run of exactly n <= 64 steps, captured the first time aps_step(n) is called
     bool graphs_built = false;
     int64_t last_graph_steps = 0, last_single_steps = 0;      // how the last aps_step call was executed
     // tiles formulation (site-centric state, one kernel per step): everything double buffered by step parity
@@ -2424,30 +2425,36 @@ constexpr int GRAPH_SIZES[NGRAPH] = {32, 16, 8, 4, 2, 1};   // steps per capture
 // one by one: runs of 32, 16, 8, 4, 2 and 1 steps are captured once -- for either parity of the first step, which the kernels'
 // buffer arguments depend on; the step index itself lives in device memory (stepw) -- and any step count is replayed as
 // a sum of those.
-int build_graphs(aps_handle *h) {
-    if (h->graphs_built) return APS_OK;
+int capture_run(aps_handle *h, int par, int nsteps, hipGraphExec_t *out) {
     if (!h->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     const bool dirty = h->slots_dirty, pending = h->field_pending, stale = h->ws_view_stale;
+    const hipStream_t user_stream = h->stream;
+    const int64_t step0 = h->step;
+    HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    h->stream = h->cap_stream;
+    h->step = par;                                           // only the parity is baked in
+    int rc = APS_OK;
+    for (int k = 0; k < nsteps && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
+    h->stream = user_stream;
+    h->step = step0;
+    h->slots_dirty = dirty; h->field_pending = pending; h->ws_view_stale = stale;      // capturing launched nothing
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { *out = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    return APS_OK;
+}
+
+int build_graphs(aps_handle *h) {
+    if (h->graphs_built) return APS_OK;
     for (int par = 0; par < 2; ++par)
         for (int g = 0; g < NGRAPH; ++g) {
-            const hipStream_t user_stream = h->stream;
-            const int64_t step0 = h->step;
-            HIP_TRY(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            h->stream = h->cap_stream;
-            h->step = par;                                   // only the parity is baked in
-            int rc = APS_OK;
-            for (int k = 0; k < GRAPH_SIZES[g] && !rc; ++k) { rc = do_propose(h); if (!rc) rc = do_commit(h); }
-            h->stream = user_stream;
-            h->step = step0;
-            hipGraph_t graph = nullptr;
-            const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
-            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            if (ce != hipSuccess) return fail(h, APS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-            const hipError_t ie = hipGraphInstantiate(&h->gexec[par][g], graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { h->gexec[par][g] = nullptr; return fail(h, APS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            int rc = capture_run(h, par, GRAPH_SIZES[g], &h->gexec[par][g]);
+            if (rc) return rc;
         }
-    h->slots_dirty = dirty; h->field_pending = pending; h->ws_view_stale = stale;      // capturing launched nothing
     h->graphs_built = true;
     return APS_OK;
 }
@@ -2455,6 +2462,8 @@ int build_graphs(aps_handle *h) {
 void drop_graphs(aps_handle *h) {
     for (int par = 0; par < 2; ++par)
         for (int g = 0; g < NGRAPH; ++g) if (h->gexec[par][g]) { (void)hipGraphExecDestroy(h->gexec[par][g]); h->gexec[par][g] = nullptr; }
+    for (int par = 0; par < 2; ++par)
+        for (int n = 0; n <= 64; ++n) if (h->gexact[par][n]) { (void)hipGraphExecDestroy(h->gexact[par][n]); h->gexact[par][n] = nullptr; }
     h->graphs_built = false;
 }
 
@@ -2537,6 +2546,15 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     h->last_graph_steps = h->last_single_steps = 0;
     if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps > 0) {
         if ((rc = build_graphs(h))) return rc;                             // once per handle, on the first stepping call
+        if (nsteps <= 64 && nsteps != 32 && nsteps != 16 && nsteps != 8 && nsteps != 4 && nsteps != 2 && nsteps != 1) {
+            // a short call that is not one of the stock sizes: one graph of exactly that many steps (captured on first use),
+            // one launch instead of several
+            hipGraphExec_t &ge = h->gexact[h->step & 1][nsteps];
+            if (!ge && (rc = capture_run(h, (int)(h->step & 1), (int)nsteps, &ge))) return rc;
+            HIP_TRY(h, hipGraphLaunch(ge, h->stream));
+            h->step += nsteps; h->last_graph_steps += nsteps; s = nsteps;
+            if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true; }
+        }
         for (int g = 0; g < NGRAPH; ++g)
             for (; nsteps - s >= GRAPH_SIZES[g]; s += GRAPH_SIZES[g]) {
                 HIP_TRY(h, hipGraphLaunch(h->gexec[h->step & 1][g], h->stream));
