@@ -143,6 +143,11 @@ inline void weight_table(double sigma_grid, int L_, int K, bool periodic, std::v
     int bits = 0;
     while (std::ldexp(1.0, bits) <= bound) ++bits;
     int q = std::min(45, sum_bits - bits);
+    if (sum_bits < 32) {                                     // integer field: every single weight below 2^23 (24-bit multiply-add)
+        int wb = 0;
+        while (std::ldexp(1.0, wb) <= std::ceil(wmax)) ++wb;
+        q = std::min(q, 22 - wb);
+    }
     const double up = std::ldexp(1.0, q), down = std::ldexp(1.0, -q);
     int n = 0;
     for (int64_t t = 0; t <= tmax; ++t) {

@@ -93,7 +93,7 @@ __device__ __forceinline__ W ts_table_at(const W *__restrict__ table_g, uint32_t
 }
 
 __device__ __forceinline__ void ts_acc(double &acc, double w, int c) { acc = fma(w, (double)c, acc); }
-__device__ __forceinline__ void ts_acc(int &acc, int w, int c) { acc += w * c; }
+__device__ __forceinline__ void ts_acc(int &acc, int w, int c) { acc += __mul24(w, c); }   // |w| < 2^23 by construction of the table: v_mad_i32_i24, full rate
 
 // |a - b| + c with b wave-uniform (a deposit's site * 8 in a scalar register)
 __device__ __forceinline__ uint32_t sad3s(uint32_t a, uint32_t b_uniform, uint32_t c) {
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         // Window j (distances [(jH - 1) OWN - 2, (jH + H) OWN + 2]) is double buffered and requested one group ahead by
         // LDS-direct loads; list words likewise.  Shared lists: double buffered; their packed lengths: triple buffered.
         constexpr int H = TS_WH;
+        static_assert(2 * H * 16 == FU_THREADS, "one list load per lane: 2 H buckets x 16 slots = the workgroup");
         uint32_t *shl = seg_all;                               // [2][3][TS_SHCAP], over the per-wave segments (unused here)
         int *scnt = misc + 8;                                  // [3][2]: lengths nP | nM << 10 | nF << 20, "a bucket has more than 16" flag
         const int side = max(tile - b0, b0 + nbk - 1 - tile);

@@ -145,6 +145,11 @@ int32_t orc_build_table_bits(double sigma_g, int32_t L, int32_t K, int32_t perio
     while (ldexp(1.0, bits) <= bound) ++bits;       /* bit length of the integer bound */
     int q = sum_bits - bits;
     if (q > 45) q = 45;
+    if (sum_bits < 32) {                            /* integer field: every single weight below 2^23 (24-bit multiply-add) */
+        int wb = 0;
+        while (ldexp(1.0, wb) <= ceil(wmax)) ++wb;
+        if (q > 22 - wb) q = 22 - wb;
+    }
     const double up = ldexp(1.0, q), down = ldexp(1.0, -q);
     int32_t n = 0;
     for (int64_t t = 0; t <= tmax; ++t) {

@@ -2,6 +2,8 @@ import os, sys, time, importlib
 sys.path.insert(0, ".")
 import bench
 capi = importlib.import_module(bench.PKG + ".capi")
+if os.environ.get("APS_LIB"):                      # an alternative build of the library (tuning experiments)
+    capi.LIB_PATH = os.environ["APS_LIB"]
 wl = sys.argv[1]; fp32 = bool(int(sys.argv[2]))
 w = dict(bench.WORK) if wl == "config2" else dict(bench.EXTRA[wl])
 h = capi.Handle(L=w["L"], K=1, periodic=False, sigma_grid=w["sigma"] * w["L"], rate_diffusion=w["rate_diffusion"], rate_active=w["rate_active"],
