@@ -430,17 +430,22 @@ def main():
             ranks_seen = dist.get_world_size()
             if site_shards:
                 left, right = rank - 1, rank + 1
+                recv_sizes = h.halo_sizes()[1]
 
                 def run(n):
                     for _ in range(int(n)):
                         h.propose()
-                        first, last = torch.from_numpy(h.halo_pack(0).copy()), torch.from_numpy(h.halo_pack(1).copy())
+                        if not h.halo_info()[2]:             # the ghost zone still covers this step: no exchange
+                            h.commit()
+                            continue
                         reqs, from_left, from_right = [], None, None
                         if left >= 0:
-                            from_left = torch.zeros(len(last), dtype=torch.uint8)
+                            first = torch.from_numpy(h.halo_pack(0).copy())
+                            from_left = torch.zeros(recv_sizes[1], dtype=torch.uint8)
                             reqs += [dist.isend(first, left), dist.irecv(from_left, left)]
                         if right < world:
-                            from_right = torch.zeros(len(first), dtype=torch.uint8)
+                            last = torch.from_numpy(h.halo_pack(1).copy())
+                            from_right = torch.zeros(recv_sizes[0], dtype=torch.uint8)
                             reqs += [dist.isend(last, right), dist.irecv(from_right, right)]
                         for q in reqs:
                             q.wait()
@@ -488,7 +493,11 @@ def main():
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             assert bool((lo == hi).all()), "ranks diverged"
         comm_path = path
-        sharding_note = ("site ranges of one system over %d GPU(s), per step a halo of 3 sites + the deposit lists within reach to each neighbour" % world
+        if site_shards:
+            k_halo = h.halo_info()[0]
+            extra.update({"halo_interval": k_halo, "halo_bytes_per_message": max(h.halo_sizes()[0])})
+        sharding_note = (("site ranges of one system over %d GPU(s); every %d step(s) one message to each neighbour rank (the ghost tiles this "
+                          "rank steps redundantly in between: cells, {W,S}, deposit lists)" % (world, k_halo))
                          if site_shards else "particle index over %d GPU(s), 1 all-gather of 1 B/particle per step" % world) + f" ({path})"
         n_ens_total = n_ens
     else:

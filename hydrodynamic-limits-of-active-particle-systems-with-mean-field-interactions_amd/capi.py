@@ -38,7 +38,7 @@ class ApsParams(C.Structure):
         ("k_off", C.c_double), ("k_exit", C.c_double), ("dt", C.c_double), ("seed", C.c_uint64),
         ("beta", C.POINTER(C.c_double)), ("anchor_mask", C.POINTER(C.c_uint8)), ("device", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("sort_by_site", C.c_int32),
-        ("ensemble_base", C.c_int32), ("method", C.c_int32), ("fp32", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("ensemble_base", C.c_int32), ("method", C.c_int32), ("fp32", C.c_int32), ("halo_interval", C.c_int32),
     ]
 
 
@@ -120,6 +120,8 @@ def load():
         "aps_halo_copy": (C.c_int, [vp, vp]),
         "aps_halo_pack": (C.c_int, [vp, i32, vp, i64, P(i64)]),
         "aps_halo_unpack": (C.c_int, [vp, i32, vp, i64]),
+        "aps_halo_info": (C.c_int, [vp, P(i32), P(i32), P(i32)]),
+        "aps_halo_sizes": (C.c_int, [vp, P(i64), P(i64)]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -139,7 +141,7 @@ class Handle:
     def __init__(self, *, L, K, periodic, sigma_grid, rate_diffusion, rate_active, beta, dt, seed,
                  n_particles, minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False,
                  k_on=0.0, k_off=0.0, k_exit=0.0, anchor_mask=None, device=0, rank=0, world=1,
-                 sort_by_site=True, ensemble_base=0, method="auto", fp32=False):
+                 sort_by_site=True, ensemble_base=0, method="auto", fp32=False, halo_interval=0):
         self.lib = load()
         self._h = C.c_void_p()
         betas = np.atleast_1d(np.asarray(beta, dtype=np.float64)).copy()
@@ -158,7 +160,7 @@ class Handle:
                         anchor_mask=None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_uint8)),
                         device=int(device), rank=int(rank), world=int(world),
                         sort_by_site=int(bool(sort_by_site)), ensemble_base=int(ensemble_base), method=METHODS[method],
-                        fp32=int(bool(fp32)))
+                        fp32=int(bool(fp32)), halo_interval=int(halo_interval))
         rc = self.lib.aps_create(C.byref(par), C.byref(self._h))
         if rc != APS_OK:
             raise ApsError(rc, self.lib.aps_last_error(None).decode())
@@ -250,6 +252,18 @@ class Handle:
     def halo_from(self, neighbour):
         """Copy the halo this handle needs from a neighbour rank's handle on the same device (between propose and commit)."""
         self._ck(self.lib.aps_halo_copy(self._h, neighbour._h))
+
+    def halo_info(self):
+        """(steps per halo exchange, steps since the last one, exchange due between this propose and its commit)"""
+        k, age, due = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.aps_halo_info(self._h, C.byref(k), C.byref(age), C.byref(due)))
+        return int(k.value), int(age.value), bool(due.value)
+
+    def halo_sizes(self):
+        """((first block, last block) this rank sends, (right neighbour's first, left neighbour's last) it receives), bytes"""
+        snd, rcv = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        self._ck(self.lib.aps_halo_sizes(self._h, snd, rcv))
+        return (int(snd[0]), int(snd[1])), (int(rcv[0]), int(rcv[1]))
 
     def halo_pack(self, side):
         """This rank's first (side 0) / last (side 1) halo block as a uint8 array (between propose and commit)."""

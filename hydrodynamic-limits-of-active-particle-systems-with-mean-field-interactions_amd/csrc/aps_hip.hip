@@ -1396,6 +1396,10 @@ struct aps_handle {
     int2 *d_wsi[2] = {nullptr, nullptr};
     // site-range sharding of the tiles formulation: this rank steps tiles [ts_lo, ts_hi) = sites [own_lo, own_hi)
     int ts_lo = 0, ts_hi = 0, own_lo = 0, own_hi = 0, ts_reach = 0;
+    // steps per halo exchange (ghost zone of (ts_kx - 1) * ts_reach tiles per side stepped redundantly), steps since the
+    // last exchange, and which neighbour blocks of a due exchange have arrived (bit 0: the right one's, bit 1: the left one's)
+    int ts_kx = 1, halo_age = 0;
+    unsigned halo_got = 0;
     // packed halo messages: [0] this rank's first block (for the left neighbour) / the block received from the RIGHT neighbour
     // (its first block); [1] this rank's last block / the block received from the LEFT neighbour (its last block)
     char *d_halo_send[2] = {nullptr, nullptr}, *d_halo_recv[2] = {nullptr, nullptr};
@@ -1815,6 +1819,24 @@ void ts_choose_geometry(aps_handle *h) {
     h->own_lo = h->ts_lo * h->ts_own;
     h->own_hi = std::min(L, h->ts_hi * h->ts_own);
     h->ts_reach = h->model.field_mode ? (h->tlen + 2 + h->ts_own - 1) / h->ts_own : 0;
+    // steps per halo exchange: the ghost tiles a rank steps on top of its own cost nothing while the launch stays within
+    // one workgroup per CU (the step is latency bound there), and at most a quarter more otherwise
+    h->ts_kx = 1;
+    if (h->world > 1) {
+        const int reach = std::max(h->ts_reach, 1);
+        int own_min = h->ts_ntile, own_max = 0;
+        for (int r = 0; r < h->world; ++r) {
+            const int n = (int)((int64_t)(r + 1) * h->ts_ntile / h->world) - (int)((int64_t)r * h->ts_ntile / h->world);
+            own_min = std::min(own_min, n); own_max = std::max(own_max, n);
+        }
+        auto fits = [&](int k) { return k * reach <= own_min && own_max + 2 * (k - 1) * reach <= h->ts_ntile; };
+        const int64_t budget = std::max<int64_t>(256 / std::max(h->E, 1), (int64_t)own_max + own_max / 4);
+        int k = 1;
+        while (k < 8 && fits(k + 1) && own_max + 2 * k * reach <= budget) ++k;
+        if (h->p.halo_interval > 0) k = h->p.halo_interval;
+        else if (const char *env = std::getenv("APS_HALO_INTERVAL")) k = std::max(1, std::atoi(env));
+        h->ts_kx = k;                                  // aps_create refuses an interval that does not fit
+    }
 }
 
 TileArgs tile_args(aps_handle *h, bool field_only) {
@@ -1838,9 +1860,13 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
     if (rc) return rc;
     TileArgs a = tile_args(h, field_only);
     int t0 = h->ts_lo, t1 = h->ts_hi;
-    if (field_only && h->world > 1) {        // also the neighbours' boundary tiles: they hold the two halo sites this rank's frames read
-        t0 = h->p.periodic ? t0 - 1 : std::max(0, t0 - 1);
-        t1 = h->p.periodic ? t1 + 1 : std::min(h->ts_ntile, t1 + 1);
+    if (h->world > 1) {
+        // the ghost tiles whose inputs are still complete `halo_age` steps after the exchange; a flush also covers the
+        // next tile on either side: it holds the two halo sites the outermost frames read
+        if (!field_only && h->halo_age >= h->ts_kx) return fail(h, APS_ERR_STATE, "tiles, sharded: the halo exchange of the last step is missing");
+        const int g = (h->ts_kx - 1 - std::min(h->halo_age, h->ts_kx - 1)) * h->ts_reach + (field_only ? 1 : 0);
+        t0 = h->p.periodic ? t0 - g : std::max(0, t0 - g);
+        t1 = h->p.periodic ? t1 + g : std::min(h->ts_ntile, t1 + g);
     }
     const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1, h->f32);
     const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total;
@@ -1874,10 +1900,15 @@ struct HaloSeg { size_t off, bytes; int array; };   // array: 0 cells, 1 ws, 2 d
 void halo_segments(const aps_handle *h, int owner_lo_tile, int owner_hi_tile, int side, std::vector<HaloSeg> &out) {
     const int L = h->p.L, K = h->p.K, own = h->ts_own;
     const int s_lo = owner_lo_tile * own, s_hi = std::min(L, owner_hi_tile * own);
-    const int nt = std::min(h->ts_reach, owner_hi_tile - owner_lo_tile);
+    const int nt = std::min(h->ts_kx * h->ts_reach, owner_hi_tile - owner_lo_tile);
+    // whole tiles of cells and {W, S}: the ghost zone the receiver steps itself between two exchanges
+    const int64_t gs = (int64_t)(h->ts_kx - 1) * h->ts_reach * own;
     for (int e = 0; e < h->E; ++e) {
-        const int c0 = side == 0 ? s_lo : std::max(s_lo, s_hi - 3), c1 = side == 0 ? std::min(s_hi, s_lo + 3) : s_hi;
-        const int w0 = side == 0 ? s_lo : std::max(s_lo, s_hi - 2), w1 = side == 0 ? std::min(s_hi, s_lo + 2) : s_hi;
+        const int64_t g1 = std::min<int64_t>(s_hi, (int64_t)owner_hi_tile * own - gs);      // first site of the last ghost tiles
+        const int c0 = side == 0 ? s_lo : (int)std::max<int64_t>(s_lo, g1 - 3);
+        const int c1 = side == 0 ? (int)std::min<int64_t>(s_hi, s_lo + gs + 3) : s_hi;
+        const int w0 = side == 0 ? s_lo : (int)std::max<int64_t>(s_lo, g1 - 2);
+        const int w1 = side == 0 ? (int)std::min<int64_t>(s_hi, s_lo + gs + 2) : s_hi;
         const int t0 = side == 0 ? owner_lo_tile : owner_hi_tile - nt, t1 = t0 + nt;
         out.push_back({((size_t)e * L + c0) * K * 4, (size_t)(c1 - c0) * K * 4, 0});
         if (h->model.field_mode) {
@@ -1956,6 +1987,15 @@ int halo_launch(aps_handle *h, int side, bool unpack) {
 }
 
 // after the tile kernel of a step: one packed message to each neighbour rank, one from each (ncclSend / ncclRecv in one group)
+// the neighbour blocks a due exchange must bring in (bit 0: the right neighbour's first block, bit 1: the left one's last)
+unsigned halo_expected(const aps_handle *h) {
+    int left, right;
+    halo_peers(h, left, right);
+    return (right >= 0 && h->halo_nseg_recv[0] ? 1u : 0u) | (left >= 0 && h->halo_nseg_recv[1] ? 2u : 0u);
+}
+
+bool halo_due(const aps_handle *h) { return h->world > 1 && h->halo_age + 1 == h->ts_kx; }
+
 int halo_exchange_rccl(aps_handle *h) {
     int left, right, rc;
     halo_peers(h, left, right);
@@ -1973,6 +2013,7 @@ int halo_exchange_rccl(aps_handle *h) {
     if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("halo exchange (ncclSend/ncclRecv): ") + g_rccl.GetErrorString(nr));
     if (right >= 0 && (rc = halo_launch(h, 0, true))) return rc;
     if (left >= 0 && (rc = halo_launch(h, 1, true))) return rc;
+    h->halo_got = halo_expected(h);
     return APS_OK;
 }
 
@@ -2053,6 +2094,8 @@ int ensure_tiles(aps_handle *h) {
     h->d_ws = h->d_wsb[cur];
     h->field_dirty = false;
     h->field_pending = false;
+    h->halo_age = 0;                                         // built from the whole uploaded state: every tile is complete
+    h->halo_got = 0;
     return APS_OK;
 }
 
@@ -2087,7 +2130,17 @@ int do_propose(aps_handle *h) {
 }
 
 int do_commit(aps_handle *h) {
-    if (is_tiles(h)) { h->step += 1; return prof_mark(h, KIND_END); }   // the tile kernel already wrote the new state
+    if (is_tiles(h)) {                                       // the tile kernel already wrote the new state
+        if (h->world > 1) {
+            if (halo_due(h)) {
+                if (h->halo_got != halo_expected(h)) return fail(h, APS_ERR_STATE, "aps_commit: the halo exchange is due before this commit (aps_halo_info)");
+                h->halo_age = 0;
+            } else h->halo_age += 1;
+            h->halo_got = 0;
+        }
+        h->step += 1;
+        return prof_mark(h, KIND_END);
+    }
     const CommitArgs c = commit_args(h);
     const dim3 grid((unsigned)(h->Npad / 256), (unsigned)h->E), block(256);
     int rc;
@@ -2229,6 +2282,12 @@ int aps_create(const aps_params *p, aps_handle **out) {
             (rc = dev_alloc(h, &h->d_stepw, 2)))
             return die(rc);
     }
+    if (h->method == APS_METHOD_TILES && h->world > 1 && (h->ts_kx < 1 || h->ts_kx * std::max(h->ts_reach, 1) > h->ts_ntile / h->world ||
+                                                         (h->ts_ntile + h->world - 1) / h->world + 2 * (h->ts_kx - 1) * h->ts_reach > h->ts_ntile)) {
+        h->err = "tiles, sharded: halo_interval " + std::to_string(h->ts_kx) + " x reach " + std::to_string(h->ts_reach) +
+                 " tiles does not fit a rank's tile range (" + std::to_string(h->ts_ntile / h->world) + " tiles)";
+        return die(APS_ERR_ARG);
+    }
     if (h->method == APS_METHOD_TILES && h->world > 1 && 2 * h->ts_reach + 1 > h->ts_ntile / h->world) {
         h->err = "tiles, sharded: the table's reach (" + std::to_string(h->ts_reach) + " tiles) must stay below half a rank's tile range (" +
                  std::to_string(h->ts_ntile / h->world) + " tiles): fewer ranks or a larger lattice";
@@ -2248,7 +2307,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
         }
         if ((rc = dev_alloc(h, &h->d_model, 1)) || (rc = dev_alloc(h, &h->d_rare, 1))) return die(rc);
         {
-            const TileRare rare{h->d_exit, h->d_nexit, h->d_src, h->d_slot_of, h->d_stamps, (long long)h->N, h->exit_cap, (int)h->Npad};
+            const TileRare rare{h->d_exit, h->d_nexit, h->d_src, h->d_slot_of, h->d_stamps, (long long)h->N, h->exit_cap, (int)h->Npad, h->ts_lo, h->ts_hi};
             if (hipMemcpyAsync(h->d_model, &h->model, sizeof(Model), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipMemcpyAsync(h->d_rare, &rare, sizeof(TileRare), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "tile argument upload failed"; return die(APS_ERR_HIP); }
@@ -2471,7 +2530,7 @@ int one_step(aps_handle *h) {
     int rc;
     if ((rc = do_propose(h))) return rc;
     if (h->comm && is_tiles(h)) {                            // site-range shards: boundary sites and deposit lists to the neighbours
-        if (h->world > 1 && (rc = halo_exchange_rccl(h))) return rc;
+        if (halo_due(h) && (rc = halo_exchange_rccl(h))) return rc;
     } else if (h->comm) {                                    // one in-place all-gather of 1 byte per particle
         const size_t block = (size_t)h->E * (size_t)h->SH;
         const ncclResult_t nr = g_rccl.AllGather(h->d_prop + block * (size_t)h->rank, h->d_prop, block, ncclUint8, h->comm, h->stream);
@@ -2876,7 +2935,9 @@ int aps_halo_copy(aps_handle *dst, aps_handle *src) {
     halo_peers(dst, left, right);
     if (src->rank != left && src->rank != right) return fail(h, APS_ERR_ARG, "aps_halo_copy: src is not a neighbour rank of dst");
     // both handles have launched this step's kernel and not yet committed: the fresh buffers are [(step & 1) ^ 1] on either side
-    if ((dst->step & 1) != (src->step & 1)) return fail(h, APS_ERR_STATE, "aps_halo_copy: the two handles are at different steps");
+    if (dst->step != src->step) return fail(h, APS_ERR_STATE, "aps_halo_copy: the two handles are at different steps");
+    if (dst->ts_kx != src->ts_kx || dst->halo_age != src->halo_age) return fail(h, APS_ERR_STATE, "aps_halo_copy: the two handles differ in halo interval or age");
+    if (!halo_due(dst)) return fail(h, APS_ERR_STATE, "aps_halo_copy: no halo exchange is due at this step (aps_halo_info)");
     int rc;
     for (int side = 0; side < 2; ++side) {                       // side 0: src's first block (src is dst's right neighbour), 1: its last
         if (src->rank != (side == 0 ? right : left)) continue;
@@ -2885,6 +2946,7 @@ int aps_halo_copy(aps_handle *dst, aps_handle *src) {
         HIP_TRY(h, hipStreamSynchronize(src->stream));
         HIP_TRY(h, hipMemcpyAsync(dst->d_halo_recv[side], src->d_halo_send[side], src->halo_bytes_send[side], hipMemcpyDeviceToDevice, dst->stream));
         if ((rc = halo_launch(dst, side, true))) return rc;
+        dst->halo_got |= 1u << side;
     }
     HIP_TRY(h, hipStreamSynchronize(dst->stream));
     return APS_OK;
@@ -2897,6 +2959,7 @@ int aps_halo_pack(aps_handle *h, int32_t side, uint8_t *host, int64_t cap, int64
     if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_pack: not a site-sharded tiles handle");
     *nbytes = (int64_t)h->halo_bytes_send[side];
     if (!host) return APS_OK;
+    if (!halo_due(h)) return fail(h, APS_ERR_STATE, "aps_halo_pack: no halo exchange is due at this step (aps_halo_info)");
     if (cap < *nbytes) return fail(h, APS_ERR_ARG, "aps_halo_pack: buffer too small");
     int rc = halo_launch(h, side, false);
     if (rc) return rc;
@@ -2910,10 +2973,31 @@ int aps_halo_unpack(aps_handle *h, int32_t from_side, const uint8_t *host, int64
     if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_unpack: not a site-sharded tiles handle");
     if (!h->halo_nseg_recv[from_side]) return fail(h, APS_ERR_ARG, "aps_halo_unpack: no neighbour on that side (reflecting wall)");
     if ((int64_t)h->halo_bytes_recv[from_side] != nbytes) return fail(h, APS_ERR_ARG, "aps_halo_unpack: byte count does not match the neighbour's block");
+    if (!halo_due(h)) return fail(h, APS_ERR_STATE, "aps_halo_unpack: no halo exchange is due at this step (aps_halo_info)");
     HIP_TRY(h, hipMemcpyAsync(h->d_halo_recv[from_side], host, (size_t)nbytes, hipMemcpyHostToDevice, h->stream));
     int rc = halo_launch(h, from_side, true);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->halo_got |= 1u << from_side;
+    return APS_OK;
+}
+
+int aps_halo_sizes(aps_handle *h, int64_t send_bytes[2], int64_t recv_bytes[2]) {
+    if (!h) return APS_ERR_ARG;
+    if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_halo_sizes: not a site-sharded tiles handle");
+    int left, right;
+    halo_peers(h, left, right);
+    if (send_bytes) { send_bytes[0] = left >= 0 ? (int64_t)h->halo_bytes_send[0] : 0; send_bytes[1] = right >= 0 ? (int64_t)h->halo_bytes_send[1] : 0; }
+    if (recv_bytes) { recv_bytes[0] = right >= 0 ? (int64_t)h->halo_bytes_recv[0] : 0; recv_bytes[1] = left >= 0 ? (int64_t)h->halo_bytes_recv[1] : 0; }
+    return APS_OK;
+}
+
+int aps_halo_info(aps_handle *h, int32_t *interval, int32_t *age, int32_t *due) {
+    if (!h) return APS_ERR_ARG;
+    const bool sharded_sites = is_tiles(h) && h->world > 1;
+    if (interval) *interval = sharded_sites ? h->ts_kx : 0;
+    if (age) *age = sharded_sites ? h->halo_age : 0;
+    if (due) *due = sharded_sites && halo_due(h) ? 1 : 0;
     return APS_OK;
 }
 

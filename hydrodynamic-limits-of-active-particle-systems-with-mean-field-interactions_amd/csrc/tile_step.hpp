@@ -26,7 +26,8 @@ constexpr uint32_t CELL_EMPTY = 0xFFFFFFFFu, CELL_ID = 0x3FFFFFFFu, CELL_BOUND =
 constexpr int TS_CREG = 4;                 // rounds of 64 cell words a wave can stage through registers (general K)
 
 // what only the rare paths (exits, diagnostic stamps) touch: kept out of the kernel's argument registers
-struct TileRare { double *exit_log; unsigned *n_exit; uint32_t *src; const uint32_t *slot_of; unsigned long long *stamps; long long N; int exit_cap, Npad; };
+struct TileRare { double *exit_log; unsigned *n_exit; uint32_t *src; const uint32_t *slot_of; unsigned long long *stamps; long long N; int exit_cap, Npad;
+                  int rec_lo, rec_hi; };   // the rank's own tiles: exits in ghost tiles (stepped redundantly) are the owner's to record
 
 struct TileArgs {
     int L, K, tlen, own, ntile, dcap, par, tile_lo, field_only, field_mode, ens_base, E;
@@ -651,13 +652,15 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             else if (ev == EV_EXIT) {
                 stays = false;
                 const TileRare R = *a.rare;
-                const unsigned kx = atomicAdd(&R.n_exit[e], 1u);
-                if ((int)kx < R.exit_cap) {
-                    double *row = R.exit_log + ((size_t)e * R.exit_cap + kx) * 3;
-                    row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
+                if (tile >= R.rec_lo && tile < R.rec_hi) {
+                    const unsigned kx = atomicAdd(&R.n_exit[e], 1u);
+                    if ((int)kx < R.exit_cap) {
+                        double *row = R.exit_log + ((size_t)e * R.exit_cap + kx) * 3;
+                        row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
+                    }
+                    R.src[(size_t)e * R.Npad + R.slot_of[(size_t)e * R.N + (c & CELL_ID)]] =
+                        (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
                 }
-                R.src[(size_t)e * R.Npad + R.slot_of[(size_t)e * R.N + (c & CELL_ID)]] =
-                    (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
                 d0 = deposit(s, -1, -sgn); nd = 1;
             }
             if (stays) { out[n_out++] = c; my_spin += (c & CELL_PLUS) ? 1 : -1; my_live += 1; }

@@ -56,7 +56,10 @@ typedef struct aps_params {
                                    every sum fits 32 bits (q = 29 - bits); W, S and the table are int32 in the stepping kernel
                                    (APS_METHOD_TILES).  Still exact integer sums -- independent of summation order, tiling and GPU
                                    count -- but a different, coarser weight table: |m - m_reference| ~ 1e-6 instead of 2e-11 */
-    int32_t reserved[1];
+    int32_t halo_interval;      /* site-sharded TILES handles: steps per halo exchange.  k > 1 keeps (k - 1) * reach tiles of the
+                                   neighbours' state as a ghost zone that this rank steps redundantly (a range shrinking by
+                                   `reach` tiles per step), so that one larger message every k steps replaces k small ones;
+                                   same bits for every k.  0: chosen by the library (aps_halo_info reports it) */
 } aps_params;
 
 /* Two formulations of compute_local_m_field (ref :216-246); both give the same bits (exact weight grid):
@@ -142,6 +145,16 @@ int aps_halo_copy(aps_handle *dst, aps_handle *src_neighbour);
  * stores a received block (from_side 0: the RIGHT neighbour's first block, 1: the LEFT neighbour's last block). */
 int aps_halo_pack(aps_handle *h, int32_t side, uint8_t *host, int64_t cap, int64_t *nbytes);
 int aps_halo_unpack(aps_handle *h, int32_t from_side, const uint8_t *host, int64_t nbytes);
+/* Steps per halo exchange of this handle (aps_params.halo_interval, or the library's choice), how many steps it has taken
+ * since the last one, and whether the exchange is due NOW, i.e. between the aps_propose just made and its aps_commit
+ * (due = 1 exactly when age + 1 == interval; a handle that is not site-sharded reports interval 0, due 0).  A caller that
+ * moves the halo itself transfers only when due; aps_commit refuses a due step whose blocks have not all arrived, and
+ * aps_halo_copy / pack / unpack refuse a step that is not due.  With interval k the blocks hold (k - 1) * reach whole
+ * tiles of cells and {W, S} (+ three / two sites) and k * reach tiles of deposit lists per side. */
+int aps_halo_info(aps_handle *h, int32_t *interval, int32_t *age, int32_t *due);
+/* Byte counts of the four blocks: send_bytes[0] / [1] = this rank's first / last block (0: no neighbour on that side),
+ * recv_bytes[0] = the RIGHT neighbour's first block, recv_bytes[1] = the LEFT neighbour's last block. */
+int aps_halo_sizes(aps_handle *h, int64_t send_bytes[2], int64_t recv_bytes[2]);
 
 /* Number of ranks the communicator of this handle actually spans (ncclCommCount): what a bench line reports as
  * evidence that the exchange ran between that many processes. */

@@ -129,15 +129,20 @@ def _tiles_worker(rank, world, port, nsteps, out_dir):
         left, right = rank - 1, rank + 1                       # reflecting walls: the end ranks have one neighbour
         for _ in range(nsteps):
             h.propose()
-            first, last = torch.from_numpy(h.halo_pack(0).copy()), torch.from_numpy(h.halo_pack(1).copy())
+            if not h.halo_info()[2]:                           # the ghost zone still covers this step: no exchange
+                h.commit()
+                continue
             reqs, from_right, from_left = [], None, None
+            recv_sizes = h.halo_sizes()[1]
             if left >= 0:
+                first = torch.from_numpy(h.halo_pack(0).copy())
                 reqs.append(dist.isend(first, left))
-                from_left = torch.zeros(len(last), dtype=torch.uint8)     # the neighbours' blocks have my blocks' sizes (same shape everywhere)
+                from_left = torch.zeros(recv_sizes[1], dtype=torch.uint8)
                 reqs.append(dist.irecv(from_left, left))
             if right < world:
+                last = torch.from_numpy(h.halo_pack(1).copy())
                 reqs.append(dist.isend(last, right))
-                from_right = torch.zeros(len(first), dtype=torch.uint8)
+                from_right = torch.zeros(recv_sizes[0], dtype=torch.uint8)
                 reqs.append(dist.irecv(from_right, right))
             for q in reqs:
                 q.wait()

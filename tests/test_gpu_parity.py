@@ -655,23 +655,30 @@ def _merged_state(handles, n):
     return pos, spin, bound, alive, seen
 
 
-@pytest.mark.parametrize("world,periodic", [(2, False), (3, False), (2, True), (4, True)])
-def test_site_sharded_tiles_equal_single_handle(capi, world, periodic):
+@pytest.mark.parametrize("world,periodic,interval,sigma", [(2, False, 1, 0.002), (3, False, 0, 0.002), (2, True, 3, 0.002), (4, True, 0, 0.002),
+                                                           (3, False, 2, 0.02), (2, True, 2, 0.02), (4, False, 5, 0.002)])
+def test_site_sharded_tiles_equal_single_handle(capi, world, periodic, interval, sigma):
     """Site-range sharding of the tiles formulation, emulated with `world` handles on ONE device: every rank steps its own
     tiles (aps_propose), the halo (3 sites of cells, 2 of {W, S}, the deposit lists within reach) is copied from the
-    neighbour handles (aps_halo_copy = what ncclSend / ncclRecv move between GPUs), aps_commit.  The merged state equals
-    the single-handle run and the oracle after every block of steps; every particle is owned by exactly one rank;
-    W, S on the own sites equal the single handle's; exits add up."""
-    par = params(L=6000, K=2, sigma=0.002, periodic=periodic, anchor_positions=[0.25, 0.5, 0.75], anchor_radius=0.02,
+    neighbour handles (aps_halo_copy = what ncclSend / ncclRecv move between GPUs), aps_commit.  With halo interval k the
+    exchange happens every k-th step only and carries (k - 1) * reach whole ghost tiles that the receiver steps itself
+    in between (interval 0: the library's choice).  The merged state equals the single-handle run and the oracle after
+    every block of steps -- blocks of 20 steps, so observations also fall between two exchanges --; every particle is
+    owned by exactly one rank; W, S on the own sites equal the single handle's; exits add up."""
+    par = params(L=6000, K=2, sigma=sigma, periodic=periodic, anchor_positions=[0.25, 0.5, 0.75], anchor_radius=0.02,
                  k_on=2.0, k_off=1.0, k_exit=0.7, rate_diffusion=3.0)
     rng = np.random.default_rng(77)
     N = 5200
     pos, spin = random_state(rng, par.L, N, par.K)
     orc = so.SyncOracle(par, dt=0.04, seed=31)
     orc.set_state(pos, spin)
-    ranks = [make_handle(capi, par, N, dt=0.04, seed=31, rank=r, world=world, method="tiles") for r in range(world)]
+    ranks = [make_handle(capi, par, N, dt=0.04, seed=31, rank=r, world=world, method="tiles", halo_interval=interval) for r in range(world)]
     single = make_handle(capi, par, N, dt=0.04, seed=31, method="tiles")
     try:
+        k = ranks[0].halo_info()[0]
+        assert k == interval if interval else k >= 1
+        assert all(h.halo_info() == (k, 0, k == 1) for h in ranks) and single.halo_info() == (0, 0, False)
+        exchanges = 0
         bounds = [h.owned_sites() for h in ranks]
         assert bounds[0][0] == 0 and bounds[-1][1] == par.L and all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))
         with pytest.raises(capi.ApsError):
@@ -682,9 +689,19 @@ def test_site_sharded_tiles_equal_single_handle(capi, world, periodic):
             for _ in range(20):
                 for h in ranks:
                     h.propose()
+                due = ranks[0].halo_info()[2]
+                assert all(h.halo_info()[2] == due for h in ranks)
+                if not due:
+                    with pytest.raises(capi.ApsError):
+                        ranks[0].halo_from(ranks[1])          # nothing to exchange at this step
+                else:
+                    if exchanges == 0 and world > 1:
+                        with pytest.raises(capi.ApsError):
+                            ranks[0].commit()                 # the blocks of a due exchange have not arrived
+                    exchanges += 1
                 for r, h in enumerate(ranks):
                     nb = {(r - 1) % world, (r + 1) % world} if periodic else {q for q in (r - 1, r + 1) if 0 <= q < world}
-                    for q in sorted(nb):
+                    for q in sorted(nb) if due else []:
                         h.halo_from(ranks[q])
                 for h in ranks:
                     h.commit()
@@ -702,6 +719,7 @@ def test_site_sharded_tiles_equal_single_handle(capi, world, periodic):
         ex = np.concatenate([h.exits() for h in ranks])
         ex = ex[np.lexsort((ex[:, 2], ex[:, 0]))]
         assert len(ex) > 0 and np.array_equal(ex, single.exits())
+        assert exchanges == 120 // k
     finally:
         for h in ranks + [single]:
             h.close()
