@@ -389,7 +389,8 @@ def main():
                 try:
                     with stdout_to_stderr():
                         h.comm_init(ids[0])
-                        h.step(1)                            # first exchange (lazy channel setup) also under the redirect
+                        h.comm_selftest()                    # ncclSend / ncclRecv rank -> itself: the transport calls work at all
+                        h.step(max(1, h.halo_info()[0]))     # up to the first exchange (lazy channel setup) also under the redirect
                 except Exception as exc:                     # noqa: BLE001
                     ok = False
                     print(f"[rank {rank}] in-library RCCL unavailable ({exc})", file=sys.stderr)

@@ -121,6 +121,7 @@ def load():
         "aps_halo_pack": (C.c_int, [vp, i32, vp, i64, P(i64)]),
         "aps_halo_unpack": (C.c_int, [vp, i32, vp, i64]),
         "aps_halo_info": (C.c_int, [vp, P(i32), P(i32), P(i32)]),
+        "aps_comm_selftest": (C.c_int, [vp, i64]),
         "aps_halo_sizes": (C.c_int, [vp, P(i64), P(i64)]),
     }
     for name, (res, args) in protos.items():
@@ -277,6 +278,10 @@ class Handle:
         """Store a neighbour's block: from_side 0 = the RIGHT neighbour's first block, 1 = the LEFT neighbour's last block."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         self._ck(self.lib.aps_halo_unpack(self._h, int(from_side), _ptr(data), len(data)))
+
+    def comm_selftest(self, nbytes=1 << 16):
+        """nbytes from this rank to itself through the halo's transport calls (ncclSend / ncclRecv in one group)."""
+        self._ck(self.lib.aps_comm_selftest(self._h, int(nbytes)))
 
     def comm_ranks(self):
         n = C.c_int32()

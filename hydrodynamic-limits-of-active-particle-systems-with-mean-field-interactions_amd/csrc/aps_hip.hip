@@ -2917,6 +2917,31 @@ int aps_comm_ranks(aps_handle *h, int32_t *nranks) {
     return APS_OK;
 }
 
+int aps_comm_selftest(aps_handle *h, int64_t nbytes) {
+    if (!h || nbytes < 1 || nbytes > (1 << 26)) return APS_ERR_ARG;
+    if (!h->comm) return fail(h, APS_ERR_STATE, "aps_comm_selftest: no communicator (aps_comm_init first)");
+    // the halo's transport calls (ncclGroupStart, ncclSend, ncclRecv, ncclGroupEnd on the handle's stream), rank -> itself
+    uint8_t *snd = nullptr, *rcv = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&snd), (size_t)nbytes));
+    if (hipMalloc(reinterpret_cast<void **>(&rcv), (size_t)nbytes) != hipSuccess) { (void)hipFree(snd); return fail(h, APS_ERR_HIP, "aps_comm_selftest: out of device memory"); }
+    std::vector<uint8_t> pat((size_t)nbytes), got((size_t)nbytes, 0);
+    for (size_t i = 0; i < pat.size(); ++i) pat[i] = (uint8_t)(i * 131u + 7u + (unsigned)h->rank);
+    hipError_t he = hipMemcpyAsync(snd, pat.data(), pat.size(), hipMemcpyHostToDevice, h->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(rcv, 0, (size_t)nbytes, h->stream);
+    ncclResult_t nr = g_rccl.GroupStart();
+    if (nr == ncclSuccess) nr = g_rccl.Send(snd, (size_t)nbytes, ncclUint8, h->rank, h->comm, h->stream);
+    if (nr == ncclSuccess) nr = g_rccl.Recv(rcv, (size_t)nbytes, ncclUint8, h->rank, h->comm, h->stream);
+    const ncclResult_t ge = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ge;
+    if (he == hipSuccess) he = hipMemcpyAsync(got.data(), rcv, got.size(), hipMemcpyDeviceToHost, h->stream);
+    const hipError_t se = hipStreamSynchronize(h->stream);
+    (void)hipFree(snd); (void)hipFree(rcv);
+    if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("aps_comm_selftest (ncclSend/ncclRecv): ") + g_rccl.GetErrorString(nr));
+    if (he != hipSuccess || se != hipSuccess) return fail(h, APS_ERR_HIP, "aps_comm_selftest: HIP error");
+    if (got != pat) return fail(h, APS_ERR_HIP, "aps_comm_selftest: received bytes differ from the bytes sent");
+    return APS_OK;
+}
+
 int aps_owned_sites(aps_handle *h, int32_t *lo, int32_t *hi) {
     if (!h) return APS_ERR_ARG;
     const bool sharded_sites = is_tiles(h) && h->world > 1;

@@ -159,6 +159,9 @@ int aps_halo_sizes(aps_handle *h, int64_t send_bytes[2], int64_t recv_bytes[2]);
 /* Number of ranks the communicator of this handle actually spans (ncclCommCount): what a bench line reports as
  * evidence that the exchange ran between that many processes. */
 int aps_comm_ranks(aps_handle *h, int32_t *nranks);
+/* nbytes through the calls the halo exchange makes (ncclGroupStart, ncclSend, ncclRecv, ncclGroupEnd on the handle's
+ * stream) from this rank to itself, compared on the host: the transport smoke test a one-GPU box can run. */
+int aps_comm_selftest(aps_handle *h, int64_t nbytes);
 
 /* replaces the observation block (ref :517-536): site histograms and the m-field on all L sites. */
 int aps_observe(aps_handle *h, int32_t ensemble, int64_t *counts_p, int64_t *counts_m, double *m_field);

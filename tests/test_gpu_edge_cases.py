@@ -113,6 +113,10 @@ def test_communicator_argument_and_ordering_errors(capi):
             a.halo_pack(0)                                                        # not a sharded handle
         a.comm_init(capi.comm_unique_id())
         assert a.comm_ranks() == 1
+        a.comm_selftest(1 << 16)                                                  # ncclSend / ncclRecv in a group, rank -> itself
+        a.comm_selftest(600_000)                                                  # the size of a k = 6 halo message
+        with pytest.raises(capi.ApsError):
+            b.comm_selftest()                                                     # no communicator
         with pytest.raises(capi.ApsError, match="already"):
             a.comm_init(capi.comm_unique_id())
         a.step(37)                                                                # step by step (a communicator disables nothing else)
