@@ -1819,8 +1819,9 @@ void ts_choose_geometry(aps_handle *h) {
     h->own_lo = h->ts_lo * h->ts_own;
     h->own_hi = std::min(L, h->ts_hi * h->ts_own);
     h->ts_reach = h->model.field_mode ? (h->tlen + 2 + h->ts_own - 1) / h->ts_own : 0;
-    // steps per halo exchange: the ghost tiles a rank steps on top of its own cost nothing while the launch stays within
-    // one workgroup per CU (the step is latency bound there), and at most a quarter more otherwise
+    // steps per halo exchange: the ghost tiles a rank steps on top of its own cost next to nothing while the launch stays
+    // within three workgroups per CU (one wave of workgroups: the step is latency bound there, 11 us at 256 tiles, 14.5 us
+    // at 633), and at most a quarter more tiles otherwise
     h->ts_kx = 1;
     if (h->world > 1) {
         const int reach = std::max(h->ts_reach, 1);
@@ -1830,7 +1831,7 @@ void ts_choose_geometry(aps_handle *h) {
             own_min = std::min(own_min, n); own_max = std::max(own_max, n);
         }
         auto fits = [&](int k) { return k * reach <= own_min && own_max + 2 * (k - 1) * reach <= h->ts_ntile; };
-        const int64_t budget = std::max<int64_t>(256 / std::max(h->E, 1), (int64_t)own_max + own_max / 4);
+        const int64_t budget = std::max<int64_t>(768 / std::max(h->E, 1), (int64_t)own_max + own_max / 4);
         int k = 1;
         while (k < 8 && fits(k + 1) && own_max + 2 * k * reach <= budget) ++k;
         if (h->p.halo_interval > 0) k = h->p.halo_interval;
