@@ -51,7 +51,7 @@ __host__ __device__ inline int ts_table_pad(int RS, int own) { return 64 * RS + 
 __host__ __device__ inline int ts_table_chunks(int tlen, int RS, int own, int wbytes) { return ((tlen + ts_table_pad(RS, own) + 1) * wbytes + 1023) / 1024; }   // 1 KB each
 constexpr int TS_WH = 8;                   // windowed sweep: bucket offsets per group (buckets tile - off and tile + off, off in [jH, jH + H))
 __host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TS_WH + 1) * own + 64 * RS + 8 + 127) / 128 * 128; }
-constexpr int TS_SHCAP = 320;              // windowed sweep: capacity of a shared class list (a round adds at most 256 entries)
+constexpr int TS_SHCAP = 320;              // windowed sweep: capacity of a shared class list (a round adds at most 256 entries); per side: half
 constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
 struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
 __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K, int wbytes = 8) {
@@ -65,7 +65,7 @@ __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, i
     l.props = l.cells + ((TS + 2) * K * 4 + 7) / 8 * 8;
     l.occ = l.props + (TS * K + 7) / 8 * 8;
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
-    l.plist = l.misc + 64;
+    l.plist = l.misc + 128;
     l.tab = (l.plist + (l.cells_in_regs ? TS * (size_t)K * 8 : 0) + 15) / 16 * 16;
     const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes;
     const size_t red = (size_t)FU_WAVES * TS * 2 * wbytes;
@@ -94,7 +94,9 @@ __device__ __forceinline__ W ts_table_at(const W *__restrict__ table_g, uint32_t
 }
 
 __device__ __forceinline__ void ts_acc(double &acc, double w, int c) { acc = fma(w, (double)c, acc); }
-__device__ __forceinline__ void ts_acc(int &acc, int w, int c) { acc += __mul24(w, c); }   // |w| < 2^23 by construction of the table: v_mad_i32_i24, full rate
+// |w| < 2^23 by construction of the table: v_mad_i32_i24, full rate.  Written as assembly: the compiler reassociates the
+// integer sums of a group into multiplies + three-operand adds (30 instructions for 20 multiply-adds).  c is wave-uniform.
+__device__ __forceinline__ void ts_acc(int &acc, int w, int c) { asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "s"(c)); }
 
 // |a - b| + c with b wave-uniform (a deposit's site * 8 in a scalar register)
 __device__ __forceinline__ uint32_t sad3s(uint32_t a, uint32_t b_uniform, uint32_t c) {
@@ -143,6 +145,68 @@ __device__ __forceinline__ void ts_group(const uint4 q, const uint32_t (&x8)[RS]
 #pragma unroll
         for (int r = 0; r < RS; ++r) ts_acc(acc[r], w[k][r], c);
     }
+}
+
+// The same for four deposits that all lie on ONE side of the whole frame, table window in LDS (windowed sweep, groups j >= 1):
+// the lane's RS sites are 64 apart, so their distances to a deposit are too -- one subtraction gives the address of the
+// nearest row and the other rows are immediate offsets of the LDS reads (6 VALU per deposit x RS rows instead of 2 RS).
+// DIR 0: deposits right of the frame, xb = x8[RS - 1] - window base;  DIR 1: left of it, xb = x8[0] + window base.
+// Used with the 32-bit field only: binary64 rows 64 entries apart get merged into ds_read2st64_b64, half the LDS rate of
+// separate ds_read_b64 (MI355X_MICROARCH.md, LDS table), and forcing separate reads (measured) still lost to the plain
+// |x - p| form with one list per class -- the binary64 sweep is LDS bound, not VALU bound.
+template <int RS, int MODE, bool F32, int DIR>
+__device__ __forceinline__ void ts_group_dir(const uint4 q, const uint32_t xb, typename TsField<F32>::w_t (&acc)[RS]) {
+    using W = typename TsField<F32>::w_t;
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    typedef __attribute__((address_space(3))) const W lds_cw;
+    constexpr int SH = TsField<F32>::SH;
+    const uint32_t ent[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
+    W w[4][RS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t p8 = (ent[k] & POS_MASK) << SH;
+        lds_cc *a0 = reinterpret_cast<lds_cc *>(DIR == 0 ? p8 - xb : xb - p8);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) w[k][r] = *reinterpret_cast<lds_cw *>(a0 + ((DIR == 0 ? RS - 1 - r : r) * (64 << SH)));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = MODE == 0 ? (int)((ent[k] >> 27) & 3u) - 1 : (int)(ent[k] >> 29) - 2;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) ts_acc(acc[r], w[k][r], c);
+    }
+}
+
+// one deposit (the last one to three of a list: no padding to whole groups)
+template <int RS, int MODE, bool F32, int DIR>
+__device__ __forceinline__ void ts_one_dir(const uint32_t entry, const uint32_t xb, typename TsField<F32>::w_t (&acc)[RS]) {
+    using W = typename TsField<F32>::w_t;
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    typedef __attribute__((address_space(3))) const W lds_cw;
+    constexpr int SH = TsField<F32>::SH;
+    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry);
+    const uint32_t p8 = (ent & POS_MASK) << SH;
+    W w[RS];
+    lds_cc *a0 = reinterpret_cast<lds_cc *>(DIR == 0 ? p8 - xb : xb - p8);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) w[r] = *reinterpret_cast<lds_cw *>(a0 + ((DIR == 0 ? RS - 1 - r : r) * (64 << SH)));
+    const int c = MODE == 0 ? (int)((ent >> 27) & 3u) - 1 : (int)(ent >> 29) - 2;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) ts_acc(acc[r], w[r], c);
+}
+
+template <int RS, int MODE, bool F32>
+__device__ __forceinline__ void ts_one_abs(const uint32_t entry, const uint32_t (&x8)[RS], const uint32_t tbase, typename TsField<F32>::w_t (&acc)[RS]) {
+    using W = typename TsField<F32>::w_t;
+    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry);
+    const uint32_t p8 = (ent & POS_MASK) << TsField<F32>::SH;
+    W w[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) w[r] = ts_table_at<true, W>(nullptr, sad3s(x8[r], p8, tbase));
+    const int c = MODE == 0 ? (int)((ent >> 27) & 3u) - 1 : (int)(ent >> 29) - 2;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) ts_acc(acc[r], w[r], c);
 }
 
 // Inside the kernel sites carry a bias so that the mirror images of deposits beyond a reflecting wall (sites -1 - p and
@@ -216,7 +280,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
         typedef __attribute__((address_space(3))) W lds_w;
         tbase = (uint32_t)(size_t)(lds_w *)tab;               // LDS byte offset of the table (or of the windows)
     }
-    if (t < 16) misc[t] = 0;                                   // counters used before the first data barrier (particle list)
+    if (t < 32) misc[t] = 0;                                   // counters used before the first data barrier (particle list)
     __syncthreads();
 #ifdef APS_STAMPS
     unsigned long long f_cnt = 0, f_stage = 0, f_copy = 0, f_proc = 0, f_part = 0, f_n = 0, t0 = __builtin_amdgcn_s_memtime();
@@ -392,14 +456,21 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     if (!TAB_LDS && windowed) {
         // Table beyond LDS, interior tile.  The buckets at offsets -off and +off from this tile are at the same distances,
         // so they share one window of the table: group j = offsets [jH, jH + H) on both sides (16 buckets x 16 list slots =
-        // one load per lane).  The four waves pool a group's deposits into SHARED per-class lists (one LDS atomic per wave),
-        // and every wave then takes whole groups of four from those lists: no per-wave padding, half the barriers.
+        // one load per lane).  The four waves pool a group's deposits into SHARED lists per (side, class) -- a wave's buckets
+        // are all on one side (waves 0, 2: right of the tile, 1, 3: left), one LDS atomic per wave -- and every wave then
+        // takes whole groups of four from those lists: no per-wave padding, half the barriers.  From group 1 on every deposit
+        // lies on one side of the whole frame (ts_group_dir).
         // Window j (distances [(jH - 1) OWN - 2, (jH + H) OWN + 2]) is double buffered and requested one group ahead by
         // LDS-direct loads; list words likewise.  Shared lists: double buffered; their packed lengths: triple buffered.
         constexpr int H = TS_WH;
         static_assert(2 * H * 16 == FU_THREADS, "one list load per lane: 2 H buckets x 16 slots = the workgroup");
-        uint32_t *shl = seg_all;                               // [2][3][TS_SHCAP], over the per-wave segments (unused here)
-        int *scnt = misc + 8;                                  // [3][2]: lengths nP | nM << 10 | nF << 20, "a bucket has more than 16" flag
+        // the 32-bit field splits the lists by side (directional gathers from group 1 on); with the binary64 field the
+        // gathers are LDS bound either way and the shorter lists only cost pipeline fills: one list per class
+        constexpr int NSIDE = F32 ? 2 : 1, CAP = TS_SHCAP / NSIDE;
+        uint32_t *shl = seg_all;                               // [2][NSIDE][3][CAP], over the per-wave segments (unused here)
+        static_assert(2 * 3 * TS_SHCAP <= FU_WAVES * 4 * (TS_SEG + 4), "the shared lists fit the segments' space");
+        int *scnt = misc + 8;                                  // [3][3]: per side the lengths nP | nM << 10 | nF << 20, "a bucket has more than 16" flag
+        const int side_w = F32 ? (wave & 1) : 0;               // wave & 1 = bsel & 1: this wave's buckets are tile - off (1) or tile + off (0)
         const int side = max(tile - b0, b0 + nbk - 1 - tile);
         const int ngr = side / H + 1;
         const int bsel = (lane >> 4) * FU_WAVES + wave, sl16 = lane & 15;
@@ -441,19 +512,18 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                 const unsigned long long mP = __ballot(cP), mM = __ballot(cM), mF = __ballot(cF);
                 const int add = __popcll(mP) | (__popcll(mM) << 10) | (__popcll(mF) << 20);
                 int base = 0;
-                if (lane == 0 && add) base = atomicAdd(&scnt[j3 * 2], add);
+                if (lane == 0 && add) base = atomicAdd(&scnt[j3 * 3 + side_w], add);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (__ballot((uint32_t)sl16 + 16u <= cnt && cnt > 16u) && lane == 0) atomicOr(&scnt[j3 * 2 + 1], 1);
-                uint32_t *lst = shl + (size_t)jj * 3 * TS_SHCAP;
-#define TS_POOL(COND, MASK, SHIFT, CLS) if (COND) lst[(CLS) * TS_SHCAP + ((base >> (SHIFT)) & 1023) + \
+                if (__ballot((uint32_t)sl16 + 16u <= cnt && cnt > 16u) && lane == 0) atomicOr(&scnt[j3 * 3 + 2], 1);
+                uint32_t *lst = shl + (size_t)(jj * NSIDE + side_w) * 3 * CAP;
+#define TS_POOL(COND, MASK, SHIFT, CLS) if (COND) lst[(CLS) * CAP + ((base >> (SHIFT)) & 1023) + \
                     __builtin_amdgcn_mbcnt_hi((uint32_t)((MASK) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(MASK), 0u))] = en_;
                 TS_POOL(cP, mP, 0, 0) TS_POOL(cM, mM, 10, 1) TS_POOL(cF, mF, 20, 2)
 #undef TS_POOL
             }
             __syncthreads();                                   // lists j complete, window j landed everywhere, everyone is done with group j - 1
-            if (t == 0) { scnt[((j + 2) % 3) * 2] = 0; scnt[((j + 2) % 3) * 2 + 1] = 0; }   // nobody touches that pair before the next barrier
+            if (t < 3) scnt[((j + 2) % 3) * 3 + t] = 0;        // nobody touches that triple before the next barrier
             const uint32_t wbase = win_lds + (uint32_t)(jj * WIN) * (uint32_t)WB - ((uint32_t)win_dmin(j) << SH);
-            const uint32_t padw = DEP_NULL | ((uint32_t)(j == 0 ? x0c : x1c + win_dmin(j)) + TS_BIAS);
             const uint32_t cnt_now = cnt;
             const int b_now = b;
             if (j + 1 < ngr) {                                 // next window and next list words: in flight during this sweep
@@ -463,22 +533,38 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                 if (!okb) cnt = 0u;
             }
             TSTAMP(f_cnt)
-            const int packed = scnt[j3 * 2], more = scnt[j3 * 2 + 1];
-            const int nn[3] = {packed & 1023, (packed >> 10) & 1023, (packed >> 20) & 1023};
-            int rot = wave;                                    // whole groups of four are dealt round-robin across the classes
-#define TS_SHARED(CLS, MODE, ACC) { \
-                const int n_ = nn[CLS], ng_ = (n_ + 3) >> 2; \
-                const uint4 *l4 = reinterpret_cast<const uint4 *>(shl + ((size_t)jj * 3 + (CLS)) * TS_SHCAP); \
+            const int packedR = scnt[j3 * 3], packedL = scnt[j3 * 3 + 1], more = scnt[j3 * 3 + 2];
+            int rot = wave;                                    // whole groups of four are dealt round-robin across the lists
+#define TS_SHARED(SIDE, CLS, PACKED, CALL4, CALL1) { \
+                const int n_ = ((PACKED) >> (10 * (CLS))) & 1023, nfull = n_ >> 2, rem = n_ & 3; \
+                const uint4 *l4 = reinterpret_cast<const uint4 *>(shl + ((size_t)(jj * NSIDE + (SIDE)) * 3 + (CLS)) * CAP); \
                 int g = rot & 3; \
-                uint4 q = l4[min(g, TS_SHCAP / 4 - 1)]; \
-                _Pragma("unroll 1") for (; g < ng_; g += FU_WAVES) { \
-                    const uint4 qn = l4[min(g + FU_WAVES, TS_SHCAP / 4 - 1)]; \
-                    const int left = n_ - 4 * g;               /* entries beyond the list's end -> padding */ \
-                    q.y = left > 1 ? q.y : padw; q.z = left > 2 ? q.z : padw; q.w = left > 3 ? q.w : padw; \
-                    ts_group<0, true, RS, MODE, F32>(q, x8, wbase, table_g, tlen8, L8, ACC); \
+                uint4 q = l4[min(g, CAP / 4 - 1)]; \
+                _Pragma("unroll 1") for (; g < nfull; g += FU_WAVES) { \
+                    const uint4 qn = l4[min(g + FU_WAVES, CAP / 4 - 1)]; \
+                    CALL4; \
                     q = qn; } \
-                rot = (rot - ng_) & 3; }
-            TS_SHARED(0, 0, accP) TS_SHARED(1, 0, accM) TS_SHARED(2, 1, accF)
+                if (g == nfull && rem) {                       /* the list's last one to three entries: one by one, by the wave whose turn it is */ \
+                    { const uint32_t q1 = q.x; CALL1; } \
+                    if (rem > 1) { const uint32_t q1 = q.y; CALL1; } \
+                    if (rem > 2) { const uint32_t q1 = q.z; CALL1; } } \
+                rot = (rot - nfull - (rem ? 1 : 0)) & 3; }
+            if (!F32 || j == 0) {                              // group 0 = the tile itself and its neighbours: deposits inside the frame, |x - p|
+                TS_SHARED(0, 0, packedR, (ts_group<0, true, RS, 0, F32>(q, x8, wbase, table_g, tlen8, L8, accP)), (ts_one_abs<RS, 0, F32>(q1, x8, wbase, accP)))
+                if (F32) TS_SHARED(1, 0, packedL, (ts_group<0, true, RS, 0, F32>(q, x8, wbase, table_g, tlen8, L8, accP)), (ts_one_abs<RS, 0, F32>(q1, x8, wbase, accP)))
+                TS_SHARED(0, 1, packedR, (ts_group<0, true, RS, 0, F32>(q, x8, wbase, table_g, tlen8, L8, accM)), (ts_one_abs<RS, 0, F32>(q1, x8, wbase, accM)))
+                if (F32) TS_SHARED(1, 1, packedL, (ts_group<0, true, RS, 0, F32>(q, x8, wbase, table_g, tlen8, L8, accM)), (ts_one_abs<RS, 0, F32>(q1, x8, wbase, accM)))
+                TS_SHARED(0, 2, packedR, (ts_group<0, true, RS, 1, F32>(q, x8, wbase, table_g, tlen8, L8, accF)), (ts_one_abs<RS, 1, F32>(q1, x8, wbase, accF)))
+                if (F32) TS_SHARED(1, 2, packedL, (ts_group<0, true, RS, 1, F32>(q, x8, wbase, table_g, tlen8, L8, accF)), (ts_one_abs<RS, 1, F32>(q1, x8, wbase, accF)))
+            } else if constexpr (F32) {
+                const uint32_t xbR = x8[RS - 1] - wbase, xbL = x8[0] + wbase;
+                TS_SHARED(0, 0, packedR, (ts_group_dir<RS, 0, F32, 0>(q, xbR, accP)), (ts_one_dir<RS, 0, F32, 0>(q1, xbR, accP)))
+                TS_SHARED(1, 0, packedL, (ts_group_dir<RS, 0, F32, 1>(q, xbL, accP)), (ts_one_dir<RS, 0, F32, 1>(q1, xbL, accP)))
+                TS_SHARED(0, 1, packedR, (ts_group_dir<RS, 0, F32, 0>(q, xbR, accM)), (ts_one_dir<RS, 0, F32, 0>(q1, xbR, accM)))
+                TS_SHARED(1, 1, packedL, (ts_group_dir<RS, 0, F32, 1>(q, xbL, accM)), (ts_one_dir<RS, 0, F32, 1>(q1, xbL, accM)))
+                TS_SHARED(0, 2, packedR, (ts_group_dir<RS, 1, F32, 0>(q, xbR, accF)), (ts_one_dir<RS, 1, F32, 0>(q1, xbR, accF)))
+                TS_SHARED(1, 2, packedL, (ts_group_dir<RS, 1, F32, 1>(q, xbL, accF)), (ts_one_dir<RS, 1, F32, 1>(q1, xbL, accF)))
+            }
 #undef TS_SHARED
             if (more) {                                        // rare: a bucket of this group holds more than 16 deposits -> one by one
                 for (uint32_t k0 = 16; __ballot(k0 < cnt_now); k0 += 16) {
@@ -490,11 +576,10 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
                         const int src_lane = __builtin_ctzll(mm);
                         mm &= mm - 1;
                         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)en, src_lane);
-                        const uint4 q1 = make_uint4(e1, padw, padw, padw);
                         const int cw = (int)((e1 >> 27) & 3u) - 1, cs = (int)(e1 >> 29) - 2;
-                        if (cw == 0) ts_group<0, true, RS, 1, F32>(q1, x8, wbase, table_g, tlen8, L8, accF);
-                        else if (cw == cs) ts_group<0, true, RS, 0, F32>(q1, x8, wbase, table_g, tlen8, L8, accP);
-                        else ts_group<0, true, RS, 0, F32>(q1, x8, wbase, table_g, tlen8, L8, accM);
+                        if (cw == 0) ts_one_abs<RS, 1, F32>(e1, x8, wbase, accF);
+                        else if (cw == cs) ts_one_abs<RS, 0, F32>(e1, x8, wbase, accP);
+                        else ts_one_abs<RS, 0, F32>(e1, x8, wbase, accM);
                     }
                 }
             }
