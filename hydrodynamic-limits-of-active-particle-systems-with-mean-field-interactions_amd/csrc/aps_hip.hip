@@ -1806,7 +1806,8 @@ void ts_choose_geometry(aps_handle *h) {
         if (miss < best) { best = miss; h->ts_RS = rs; }
     }
     if ((double)(((int64_t)L + 507) / 508) * h->E > 3.0 * 256.0)      // even the largest frame leaves more than 3 per CU
-        h->ts_RS = !h->f32 ? 4 : (ts_lds_layout(h->tlen, true, 6, 380, h->p.K, 4).total <= 160 * 1024 ? 6 : 7);   // measured: r02 geometry sweeps (config 5, 32-bit field: RS 4..8 = 428, 345, 347, 312, 371 us)
+        h->ts_RS = !h->f32 ? 4 : 7;   // measured (r02 geometry sweeps): binary64 config 4 RS 3..8 = 67, 59.5, 65, 62, 73, 74 us, config 5 RS 4..6 = 550, 607, 544;
+                                     // 32-bit field config 4 RS 4..8 = 56, 52, 50, 46.7, 47.4 us, config 5 = 428, 345, 347, 312, 371
     if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
     h->ts_own = 64 * h->ts_RS - 4;
     if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
