@@ -512,9 +512,12 @@ def main():
             h.step(args.steps)
             times.append(time.perf_counter() - t0)
         graph_steps, single_steps = h.step_info()
+        loop_steps, loop_state, loop_why = h.loop_info()
         elapsed = float(np.median(times))
         extra = {"repeats": len(times), "repeats_ms_per_step": [t / args.steps * 1e3 for t in times],
-                 "graph_replay": single_steps == 0, "steps_from_graphs": graph_steps, "steps_launched_singly": single_steps}
+                 "graph_replay": single_steps == 0 and loop_steps == 0, "steps_from_graphs": graph_steps, "steps_launched_singly": single_steps,
+                 # resident loop (csrc/tile_loop.hpp): steps of a timed call taken inside ONE launch, every tile resident
+                 "steps_in_resident_loop": loop_steps, "resident_loop": {1: "used", 0: "not eligible: " + loop_why, -1: "gave up: " + loop_why}.get(loop_state, "not tried")}
         hbm_copy = h.copy_bandwidth(1 << 30, 5)   # this box's streaming ceiling (read + written bytes of a 1 GiB copy)
         # per-kernel durations, timed live with HIP events on the stream the kernels are launched on
         reps = max(10, min(args.steps, 50))
@@ -545,12 +548,23 @@ def main():
             dep_per_step = deposits / max(n_fu, 1)
             N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
             algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32"))) for k in kern}
-            dom = max(kern, key=kern.get)
-            achieved = algo[dom] / kern[dom] / 1e9
             step_bytes = sum(algo.values())
+            if loop_steps > 0:
+                # the timed steps ran inside tile_loop: ONE launch = loop_steps steps; its duration from events attached to
+                # that dispatch; algorithmic bytes per launch = the per-step figure x the steps the launch takes (the state
+                # a streaming step would read and write stays on chip between the steps: that is the point of the kernel)
+                lt = [h.step_loop_timed(args.steps) for _ in range(5)]
+                assert all(n == loop_steps for _, n in lt)
+                kern["tile_loop"] = float(np.median([ms for ms, _ in lt])) * 1e-3
+                algo["tile_loop"] = algo["tile_step"] * loop_steps
+            dom = "tile_loop" if loop_steps > 0 else max(kern, key=kern.get)
+            achieved = algo[dom] / kern[dom] / 1e9
             us_step = elapsed / args.steps * 1e6
             # what limits the kernel: HBM only if the algorithmic bytes move at a sizeable fraction of the measured copy rate
-            if achieved >= 0.5 * hbm_copy:
+            if loop_steps > 0:
+                limiter = ("latency of the per-step chain inside the resident loop (wait for the neighbours' records -> deposit sweep -> "
+                           "proposals -> exclusion -> publish); the state never leaves the chip between steps")
+            elif achieved >= 0.5 * hbm_copy:
                 limiter = "hbm"
             elif L_all * (32 + 8 * w["K"]) < 200e6:
                 limiter = "latency (cache-resident working set: dependent load -> compute -> store chain of a ~10 us launch)"
@@ -567,7 +581,8 @@ def main():
                     "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step": us_step,
                                    "achieved_GBps": step_bytes / (us_step * 1e-6) / 1e9,
                                    "frac": step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                    "deposits_per_step": dep_per_step, "kernels_per_step": len(kern)}
+                    "deposits_per_step": dep_per_step, "kernels_per_step": len(kern) if loop_steps == 0 else 1.0 / loop_steps,
+                    "steps_per_launch": loop_steps if loop_steps > 0 else 1}
         roof = dict(roof or {}, **{"hbm_copy_GBps": hbm_copy})
     if not sharded_path:
         n_ens_total, sharding_note = n_ens, "one GPU"

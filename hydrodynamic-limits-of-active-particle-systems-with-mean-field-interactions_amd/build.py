@@ -14,7 +14,7 @@ SRC = os.path.join(HERE, "csrc", "aps_hip.hip")
 SRCS = [SRC, os.path.join(HERE, "csrc", "pde_hip.hip"), os.path.join(HERE, "csrc", "gillespie_hip.hip"),
         os.path.join(HERE, "csrc", "gillespie_big_hip.hip")]   # stepper; PDE solver; exact event loop
 HDR = os.path.join(ROOT, "include", "aps.h")
-HDRS = [HDR, os.path.join(ROOT, "include", "pde.h"), os.path.join(HERE, "csrc", "aps_common.hpp"), os.path.join(HERE, "csrc", "tile_step.hpp"),
+HDRS = [HDR, os.path.join(ROOT, "include", "pde.h"), os.path.join(HERE, "csrc", "aps_common.hpp"), os.path.join(HERE, "csrc", "tile_step.hpp"), os.path.join(HERE, "csrc", "tile_loop.hpp"),
         os.path.join(ROOT, "include", "gillespie.h")]
 LIB = os.path.join(HERE, "libaps_hip.so")
 ARCH = "gfx950"
@@ -26,6 +26,8 @@ def build(force=False, save_temps=False, verbose=False):
         return LIB
     cmd = ["hipcc", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-o", LIB] + SRCS
+    if os.environ.get("APS_DEV_RS"):           # development: only one frame size of the tile kernels (builds in a fraction of the time)
+        cmd += ["-DAPS_DEV_RS=" + os.environ["APS_DEV_RS"]] + (["-DAPS_LOOP_DEBUG"] if os.environ.get("APS_LOOP_DEBUG") else [])
     if save_temps:
         tmp = os.path.join(HERE, "csrc", "_temps")
         os.makedirs(tmp, exist_ok=True)

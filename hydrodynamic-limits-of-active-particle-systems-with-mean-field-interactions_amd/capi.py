@@ -102,6 +102,9 @@ def load():
         "aps_step_timed": (C.c_int, [vp, i64, P(dbl), P(i64), P(dbl)]),
         "aps_step_profile": (C.c_int, [vp, i64, vp, vp]),
         "aps_step_info": (C.c_int, [vp, P(i64), P(i64)]),
+        "aps_set_resident_loop": (C.c_int, [vp, i32]),
+        "aps_step_loop_timed": (C.c_int, [vp, i64, P(dbl), P(i64)]),
+        "aps_loop_info": (C.c_int, [vp, P(i64), P(i32), C.c_char_p, i32]),
         "aps_copy_bandwidth": (C.c_int, [vp, i64, i32, P(dbl)]),
         "aps_lattice_accumulate": (C.c_int, [vp, i32, vp, vp, vp, i64]),
         "aps_get_lattice": (C.c_int, [vp, i32, vp, vp, vp]),
@@ -304,6 +307,23 @@ class Handle:
         g, k = C.c_int64(), C.c_int64()
         self._ck(self.lib.aps_step_info(self._h, C.byref(g), C.byref(k)))
         return g.value, k.value
+
+    def set_resident_loop(self, on=True):
+        """Let step() run its steps inside one launch when every tile of the grid is resident at once (default), or not."""
+        self._ck(self.lib.aps_set_resident_loop(self._h, 1 if on else 0))
+
+    def step_loop_timed(self, nsteps):
+        """step(nsteps) with start/stop events attached to the resident loop's dispatch: (kernel ms, steps it took)."""
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.lib.aps_step_loop_timed(self._h, int(nsteps), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def loop_info(self):
+        """(steps of the last step() call taken inside the resident loop, state, reason when it is not used);
+        state: 1 usable, 0 not eligible, -1 a call gave up and was repeated with one launch per step, -2 not looked at yet."""
+        n, st, why = C.c_int64(), C.c_int32(), C.create_string_buffer(256)
+        self._ck(self.lib.aps_loop_info(self._h, C.byref(n), C.byref(st), why, 256))
+        return n.value, st.value, why.value.decode()
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=5):
         """GB/s (read + written) of a plain streaming copy kernel on this handle's device."""

@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
 }
 
 #include "tile_step.hpp"
+#include "tile_loop.hpp"
 
 // fp32 mode: the field as the tile kernel keeps it (int32, units of 2^-q) <-> the binary64 view of the other kernels; exact both ways
 __global__ __launch_bounds__(256) void ws_to_int(const double2 *__restrict__ in, int2 *__restrict__ out, size_t n, double up) {
@@ -1390,6 +1391,18 @@ struct aps_handle {
     long long *d_gpart[2] = {nullptr, nullptr};
     uint32_t *d_slot_of = nullptr;
     Model *d_model = nullptr; TileRare *d_rare = nullptr;      // device copies read by the tile kernel
+    // resident loop (tile_loop): many steps per launch while every tile of the grid is resident at once
+    unsigned long long *d_xrec = nullptr;                      // [2][E][ntile][loop_rec] exchange records (8-byte granules)
+    unsigned *d_abort = nullptr, *h_abort = nullptr, *h_abort_dev = nullptr;   // "a wait ran out": device word, host-mapped word and its device address
+    int loop_rec = 0, loop_drec = 0;
+    int loop_state = -2;                                       // -2 not looked at yet, -1 gave up once (never again), 0 not eligible, 1 usable
+    int loop_wanted = 1;                                       // aps_set_resident_loop
+    uint32_t loop_tag = 0;                                     // tags handed out so far
+    int64_t last_loop_steps = 0;
+    uint32_t *loop_dbg = nullptr; int loop_dbg_n = 0;          // APS_LOOP_DEBUG builds
+    bool loop_timed = false;                                   // the next loop launch carries start/stop events (aps_step_loop_timed)
+    hipEvent_t loop_ev[2] = {nullptr, nullptr};
+    std::string loop_why;                                      // why the loop is not used
     // fp32 mode: the tile kernel's field is int32 in units of 2^-q; d_wsb then serves as the double2 view the hooks read
     bool f32 = false, ws_view_stale = false;
     int *d_table_i = nullptr;
@@ -1780,7 +1793,11 @@ template <bool F32>
 const void *ts_kernel_f(bool periodic, bool tab, int RS, bool k1) {
 #define TS_PICK(BC, TL, R) (k1 ? (const void *)&tile_step<BC, TL, R, true, F32> : (const void *)&tile_step<BC, TL, R, false, F32>)
 #define TS_CASE(R) case R: return periodic ? (tab ? TS_PICK(1, true, R) : TS_PICK(1, false, R)) : (tab ? TS_PICK(0, true, R) : TS_PICK(0, false, R));
+#ifdef APS_DEV_RS                 /* development builds: one frame size only (compiles in a fraction of the time) */
+    switch (RS) { TS_CASE(APS_DEV_RS) default: return nullptr; }
+#else
     switch (RS) { TS_CASE(1) TS_CASE(2) TS_CASE(3) TS_CASE(4) TS_CASE(5) TS_CASE(6) TS_CASE(7) TS_CASE(8) default: return nullptr; }
+#endif
 #undef TS_CASE
 #undef TS_PICK
 }
@@ -1891,6 +1908,103 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
     }
     if (!field_only) { h->slots_dirty = true; h->field_pending = true; }
     h->ws_view_stale = true;
+    return APS_OK;
+}
+
+// ---- resident loop (tile_loop.hpp): when every tile of the grid is resident at once, aps_step runs its steps inside ONE
+// launch.  Eligible: one rank, table in LDS, a local field, no exits, the whole grid within the kernel's residency on this
+// device.  A call that gives up (a wait ran out: the workgroups were not all resident after all) leaves the inputs intact,
+// is repeated with one launch per step, and the loop is not tried again on that handle.
+template <bool F32>
+const void *tl_kernel_f(bool periodic, int RS, bool k1) {
+#define TL_PICK(BC, R) (k1 ? (const void *)&tile_loop<BC, R, true, F32> : (const void *)&tile_loop<BC, R, false, F32>)
+#define TL_CASE(R) case R: return periodic ? TL_PICK(1, R) : TL_PICK(0, R);
+#ifdef APS_DEV_RS
+    switch (RS) { TL_CASE(APS_DEV_RS) default: return nullptr; }
+#else
+    switch (RS) { TL_CASE(1) TL_CASE(2) TL_CASE(3) TL_CASE(4) TL_CASE(5) TL_CASE(6) TL_CASE(7) TL_CASE(8) default: return nullptr; }
+#endif
+#undef TL_CASE
+#undef TL_PICK
+}
+const void *tl_kernel(const aps_handle *h) {
+    return h->f32 ? tl_kernel_f<true>(h->p.periodic != 0, h->ts_RS, h->p.K == 1) : tl_kernel_f<false>(h->p.periodic != 0, h->ts_RS, h->p.K == 1);
+}
+
+int loop_prepare(aps_handle *h) {
+    if (h->loop_state != -2) return APS_OK;
+    h->loop_state = 0;
+    auto no = [&](const char *why) { h->loop_why = why; return APS_OK; };
+    if (!is_tiles(h)) return no("not the tiles formulation");
+    if (h->world != 1) return no("sharded handle");
+    if (!h->ts_table_in_lds) return no("weight table beyond LDS");
+    if (!h->model.field_mode) return no("global mean field");
+    if (h->model.immobilize && h->model.k_exit > 0.0) return no("particles can leave the system");
+    if (3 * h->p.K > 32) return no("site capacity above 10");
+    if (h->p.L - (int64_t)(h->ts_ntile - 1) * h->ts_own < 3) return no("last tile shorter than three sites");
+#ifdef APS_STAMPS
+    return no("diagnostic build");
+#endif
+    const TlLds lay = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h));
+    if (lay.total > 160 * 1024) return no("tile does not fit LDS with its state resident");
+    const void *fn = tl_kernel(h);
+    if (!fn) return no("no kernel for this frame");
+    if (lay.total > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total) != hipSuccess) { (void)hipGetLastError(); return no("hipFuncSetAttribute failed"); }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FU_THREADS, lay.total) != hipSuccess) { (void)hipGetLastError(); return no("occupancy query failed"); }
+    // The API can promise one block more than the hardware admits (MI355X_MICROARCH.md, residency).  Measured here: with
+    // 54 040 B of LDS per block the API said 3 per CU and only 2 were ever resident -- LDS is handed out in 128 granules of
+    // 1 280 B (160 KB / 128), so a block takes ceil(bytes / 1280) of them; and at most 8 blocks of 256 threads per CU.
+    const int lds_granules = (int)((lay.total + 1279) / 1280);
+    per_cu = std::min(std::min(per_cu, 8), 128 / std::max(lds_granules, 1));
+    if ((int64_t)h->ts_ntile * h->E > (int64_t)per_cu * h->num_cu) return no("more tiles than the device keeps resident at once");
+    h->loop_drec = (h->ts_dcap / 16 + 1) * 16;
+    h->loop_rec = (h->loop_drec + 6 * h->p.K + 15) / 16 * 16;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_xrec, (size_t)2 * h->E * h->ts_ntile * h->loop_rec)) || (rc = dev_alloc(h, &h->d_abort, 4))) return rc;
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_abort), 64, hipHostMallocMapped));
+    h->h_abort[0] = 0u;
+    HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->h_abort_dev), h->h_abort, 0));
+    h->loop_tag = 0;
+    h->loop_state = 1;
+    return APS_OK;
+}
+
+// n (odd) steps from the current state in one launch; the caller synchronises and looks at h_abort
+int launch_tile_loop(aps_handle *h, int64_t n) {
+    LoopArgs la{};
+    la.a = tile_args(h, false);
+    la.a.tile_lo = 0;
+    la.step0 = (unsigned long long)h->step;
+    la.nsteps = (int)n;
+    if ((uint64_t)h->loop_tag + (uint64_t)n + 2 > 0xFFFFFFF0ull) {            // tags must never repeat: start over on clean records
+        HIP_TRY(h, hipMemsetAsync(h->d_xrec, 0, (size_t)2 * h->E * h->ts_ntile * h->loop_rec * sizeof(unsigned long long), h->stream));
+        h->loop_tag = 0;
+    }
+    la.tag0 = h->loop_tag;
+    h->loop_tag += (uint32_t)n + 1u;
+    la.rec = h->loop_rec; la.drec = h->loop_drec; la.xrec = h->d_xrec;
+    la.abort_dev = h->d_abort; la.abort_host = h->h_abort_dev;
+    la.timeout_ticks = 5000000ull;                                             // 50 ms of the 100 MHz clock per wait (a hand-off takes microseconds)
+    if (const char *env = std::getenv("APS_LOOP_TIMEOUT_MS")) la.timeout_ticks = (unsigned long long)std::max(1, std::atoi(env)) * 100000ull;
+#ifdef APS_LOOP_DEBUG
+    static uint32_t *dbg = nullptr;
+    if (!dbg) (void)hipMalloc(reinterpret_cast<void **>(&dbg), (size_t)64 * 3 * h->p.L * 4);
+    (void)hipMemsetAsync(dbg, 0xEE, (size_t)64 * 3 * h->p.L * 4, h->stream);
+    la.dbg = n <= 64 ? dbg : nullptr;
+    h->loop_dbg = dbg; h->loop_dbg_n = (int)n;
+#endif
+    if (std::getenv("APS_LOOP_TEST_ABORT")) HIP_TRY(h, hipMemsetAsync(h->d_abort, 1, 4, h->stream));   // tests: the call gives up at once
+    const void *fn = tl_kernel(h);
+    const size_t lds = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total;
+    const void *table_ptr = h->f32 ? (const void *)h->d_table_i : (const void *)h->d_table;
+    void *args[] = {(void *)&la, (void *)&table_ptr};
+    const dim3 grid((unsigned)h->ts_ntile, (unsigned)h->E), block(FU_THREADS);
+    if (h->loop_timed) {
+        for (hipEvent_t &ev : h->loop_ev) if (!ev) HIP_TRY(h, hipEventCreate(&ev));
+        HIP_TRY(h, hipExtLaunchKernel(fn, grid, block, args, lds, h->stream, h->loop_ev[0], h->loop_ev[1], 0));
+    } else
+        HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, lds, h->stream));
     return APS_OK;
 }
 
@@ -2352,6 +2466,9 @@ void aps_destroy(aps_handle *h) {
     if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
     for (int b = 0; b < 2; ++b)
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
+    if (h->h_abort) (void)hipHostFree(h->h_abort);
+    for (hipEvent_t ev : h->loop_ev) if (ev) (void)hipEventDestroy(ev);
+    for (void *q : {(void *)h->d_xrec, (void *)h->d_abort}) if (q) (void)hipFree(q);
     for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)h->d_wsi[1],
                     (void *)h->d_halo_send[0], (void *)h->d_halo_send[1], (void *)h->d_halo_recv[0], (void *)h->d_halo_recv[1], (void *)h->d_halo_seg_send[0],
                     (void *)h->d_halo_seg_send[1], (void *)h->d_halo_seg_recv[0], (void *)h->d_halo_seg_recv[1]}) if (q) (void)hipFree(q);
@@ -2604,10 +2721,41 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     if (rc) return rc;
     int64_t s = 0;
     static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
-    h->last_graph_steps = h->last_single_steps = 0;
-    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps > 0) {
+    h->last_graph_steps = h->last_single_steps = h->last_loop_steps = 0;
+    int64_t loop_min = 3;                                        // below that a call is not worth the loop's set-up
+    if (const char *env = std::getenv("APS_LOOP_MIN")) loop_min = std::max(1, std::atoi(env));
+    if (is_tiles(h) && h->world == 1 && h->loop_wanted && nsteps >= loop_min && h->loop_state != 0 && h->loop_state != -1) {
+        const char *env = std::getenv("APS_TILE_LOOP");
+        if (!(env && env[0] == '0')) {
+            if ((rc = loop_prepare(h))) return rc;
+            if (h->loop_state == 1) {
+                // the loop takes an odd number of steps (its final state lands in the other parity's buffers, its inputs stay
+                // intact): an even call takes one ordinary step first
+                if (!(nsteps & 1)) { if ((rc = one_step(h))) return rc; ++s; ++h->last_single_steps; }
+                const int64_t n = std::min<int64_t>(nsteps - s, (int64_t)1 << 30 | 1);
+                if ((rc = launch_tile_loop(h, n))) return rc;
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+#ifdef APS_LOOP_DEBUG
+                if (const char *path = std::getenv("APS_LOOP_DUMP")) {
+                    std::vector<uint32_t> buf((size_t)h->loop_dbg_n * 3 * h->p.L);
+                    (void)hipMemcpy(buf.data(), h->loop_dbg, buf.size() * 4, hipMemcpyDeviceToHost);
+                    if (FILE *f = std::fopen(path, "wb")) { std::fwrite(buf.data(), 4, buf.size(), f); std::fclose(f); }
+                }
+#endif
+                if (h->h_abort[0]) {                             // the workgroups were not all resident: repeat the ordinary way, never again
+                    h->h_abort[0] = 0u;
+                    h->loop_state = -1;
+                    h->loop_why = "a wait ran out (the grid was not resident at once); steps repeated with one launch per step";
+                } else {
+                    h->step += n; s += n; h->last_loop_steps = n;
+                    h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true;
+                }
+            }
+        }
+    }
+    if ((h->method == APS_METHOD_LATTICE || is_tiles(h)) && h->world == 1 && !no_graph && nsteps > s) {
         if ((rc = build_graphs(h))) return rc;                             // once per handle, on the first stepping call
-        if (nsteps <= 64 && nsteps != 32 && nsteps != 16 && nsteps != 8 && nsteps != 4 && nsteps != 2 && nsteps != 1) {
+        if (s == 0 && nsteps <= 64 && nsteps != 32 && nsteps != 16 && nsteps != 8 && nsteps != 4 && nsteps != 2 && nsteps != 1) {
             // a short call that is not one of the stock sizes: one graph of exactly that many steps (captured on first use),
             // one launch instead of several
             hipGraphExec_t &ge = h->gexact[h->step & 1][nsteps];
@@ -2627,6 +2775,36 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     for (; s < nsteps; ++s, ++h->last_single_steps)
         if ((rc = one_step(h))) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
+int aps_set_resident_loop(aps_handle *h, int32_t on) {
+    if (!h) return APS_ERR_ARG;
+    h->loop_wanted = on ? 1 : 0;
+    return APS_OK;
+}
+
+int aps_step_loop_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *loop_steps) {
+    if (!h || !kernel_ms) return APS_ERR_ARG;
+    h->loop_timed = true;
+    const int rc = aps_step(h, nsteps);
+    h->loop_timed = false;
+    if (rc) return rc;
+    *kernel_ms = 0.0;
+    if (loop_steps) *loop_steps = h->last_loop_steps;
+    if (h->last_loop_steps > 0) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->loop_ev[0], h->loop_ev[1]));
+        *kernel_ms = ms;
+    }
+    return APS_OK;
+}
+
+int aps_loop_info(aps_handle *h, int64_t *loop_steps, int32_t *state, char *why, int32_t why_len) {
+    if (!h) return APS_ERR_ARG;
+    if (loop_steps) *loop_steps = h->last_loop_steps;
+    if (state) *state = h->loop_state;
+    if (why && why_len > 0) { std::strncpy(why, h->loop_why.c_str(), (size_t)why_len - 1); why[why_len - 1] = 0; }
     return APS_OK;
 }
 

@@ -1,0 +1,486 @@
+// tile_loop.hpp -- MANY synchronous steps in ONE launch: tile_step's step with the tiles kept resident (included by
+// aps_hip.hip after tile_step.hpp).
+//
+// Hot path replaced: the loop of ParticleSystem.run (PARTICLE_solver_CLASS.py:511-516), n iterations of
+// compute_local_m_field (:216-246) + step_gillespie (:254-448) in the fixed-dt synchronous scheme of DESIGN.md 3.
+//
+// When the whole grid of tiles is resident at once (BASELINE config 2: 633 workgroups on 256 CUs) a step of tile_step is a
+// ~14 us latency chain of which most is not the step: the launch, 37 KB of weight table staged into LDS again, the
+// tile's cells and {W, S} read back, the results written out, the drain.  Here a workgroup keeps its tile for the whole
+// call: table, cells and the frame's {W, S} stay in LDS (the field of the two halo sites either side is kept exactly too:
+// every deposit in reach is added to them as well), and between two steps a tile waits only for what it needs of its
+// neighbours -- the deposit lists of the tiles within the table's reach and three sites of cells from the tile on
+// either side.  Those travel through global memory as 8-byte {tag, word} granules (one write-through store each, polled
+// with L1-bypassing loads until the tag is this step's: cdna_hip_programming.md Guideline 16, form R2); records are
+// double buffered by step parity, which is enough because a tile cannot run more than one step ahead of a tile it
+// exchanges with.  No grid barrier, no flag, no fence.
+//
+// Safety: every wait is bounded (s_memrealtime); a workgroup that gives up raises a flag that every other wait watches,
+// all workgroups leave, and the host repeats the call with one launch per step -- the loop writes the final state only
+// into the buffers of the other parity (the step count of a launch is odd), so the inputs are still intact.  Results are
+// the same bits either way: the arithmetic and the random numbers are tile_step's.
+#pragma once
+
+constexpr int TL_SEG = 88;                 // entries per deposit segment of a wave (config 2: 3 workgroups per CU need <= 42 LDS granules of 1280 B each)
+constexpr int TL_ABORT = 31;               // misc word: this workgroup leaves (a wait ran out, here or elsewhere)
+
+struct LoopArgs {
+    TileArgs a;                            // buffers of the first step's parity: *_in = [par] (read once), *_out = [par ^ 1] (final state)
+    unsigned long long step0;              // index of the first step
+    int nsteps;                            // odd
+    uint32_t tag0;                         // the records written in iteration s carry the tag tag0 + s + 1 (never 0, never reused)
+    int rec, drec;                         // granules per record; deposit slots of a record (a multiple of 16 above dcap)
+    unsigned long long *xrec;              // [2][E][ntile][rec] {tag << 32 | word}
+    unsigned *abort_dev, *abort_host;      // raised by a workgroup whose wait ran out
+    unsigned long long timeout_ticks;      // of the 100 MHz clock
+#ifdef APS_LOOP_DEBUG
+    uint32_t *dbg;                         // [nsteps][3][L]: cells after the step, occupancy | proposal << 8 seen by the step, particles on frame
+#endif
+};
+
+struct TlLds { size_t seg, cells, cells2, props, occ, misc, plist, fw, fs, tab, total; };
+__host__ __device__ inline TlLds tl_lds_layout(int tlen, int RS, int own, int K, int wbytes) {
+    TlLds l;
+    const size_t TS = 64 * (size_t)RS, ncell = (TS + 2) * K;
+    auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    l.seg = 0;
+    l.cells = l.seg + (size_t)FU_WAVES * 4 * (TL_SEG + 4) * sizeof(uint32_t);
+    l.cells2 = up(l.cells + ncell * 4, 8);
+    l.props = up(l.cells2 + (K == 1 ? 0 : ncell * 4), 8);
+    l.occ = up(l.props + TS * K, 8);
+    l.misc = up(l.occ + TS + 2, 8);
+    l.plist = l.misc + 128;
+    l.fw = up(l.plist + TS * (size_t)K * 8, 16);
+    l.fs = l.fw + TS * wbytes;
+    l.tab = up(l.fs + TS * wbytes, 16);
+    l.total = l.tab + (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024;
+    return l;
+}
+
+typedef __attribute__((address_space(1))) unsigned long long tl_gu64;
+typedef __attribute__((address_space(1))) unsigned tl_gu32;
+
+__device__ __forceinline__ void tl_store_granule(unsigned long long *p, uint32_t tag, uint32_t word) {
+    __hip_atomic_store((tl_gu64 *)p, ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE write-through store
+}
+__device__ __forceinline__ unsigned long long tl_load_granule(const unsigned long long *p) {
+    return __hip_atomic_load((tl_gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                      // bypasses L1
+}
+
+__device__ __forceinline__ void tl_lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }       // ds_add_f64: sums are exact, the order is free
+__device__ __forceinline__ void tl_lds_add(int *p, int v) { atomicAdd(p, v); }
+
+template <int BC, int RS, bool K1, bool F32>
+__global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
+    using W = typename TsField<F32>::w_t;
+    using WS = typename TsField<F32>::ws_t;
+    constexpr int SH = TsField<F32>::SH, WB = (int)sizeof(W);
+    constexpr bool TAB_LDS = true;
+    const TileArgs &a = la.a;
+    const W *__restrict__ table_g = reinterpret_cast<const W *>(table_v);
+    constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS, NCR = (TS + 2 + FU_THREADS - 1) / FU_THREADS;
+    constexpr int SEG = TL_SEG, NSLOT = 16, GB = FU_WAVES * 4;
+    extern __shared__ double lds[];
+    const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
+    const TlLds lay = tl_lds_layout(a.tlen, RS, OWN, K, WB);
+    char *lds_c = reinterpret_cast<char *>(lds);
+    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
+    uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
+    uint32_t *cellN = reinterpret_cast<uint32_t *>(lds_c + lay.cells2);      // K > 1: the cells after this step
+    uint8_t *propL = reinterpret_cast<uint8_t *>(lds_c + lay.props);         // [TS K]
+    uint8_t *occL = reinterpret_cast<uint8_t *>(lds_c + lay.occ);            // [TS + 2]
+    int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // 0/1 deposits of this tile (by iteration parity), 2/3 particles on the frame
+    uint2 *plist = reinterpret_cast<uint2 *>(lds_c + lay.plist);
+    W *fieldW = reinterpret_cast<W *>(lds_c + lay.fw), *fieldS = reinterpret_cast<W *>(lds_c + lay.fs);   // [TS] each: the frame's field, kept across the steps
+    W *tab = reinterpret_cast<W *>(lds_c + lay.tab);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
+    uint32_t *segP = seg_all + wave * 4 * (SEG + 4), *segM = segP + SEG + 4, *segF = segM + SEG + 4, *segI = segF + SEG + 4;
+    const int tile = (int)blockIdx.x;
+    const int own0 = tile * OWN, own_n = min(OWN, L - own0), nfr = own_n + 4;
+    const int x0 = own0 - 2;
+    const int x0c = max(x0, 0), x1c = min(x0 + TS - 1, L - 1);
+    const int Rt = a.tlen - 1;
+    if (__hip_atomic_load((tl_gu32 *)la.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {        // the call was given up before this workgroup started
+        if (t == 0) __hip_atomic_store(la.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const uint32_t *__restrict__ cell_e = a.cell_in + (size_t)e * L * K;
+    const WS *__restrict__ ws_e = reinterpret_cast<const WS *>(a.ws_in) + (size_t)e * L;
+    const uint32_t *__restrict__ dcnt_e = a.dcnt_in + (size_t)e * a.ntile;
+    const uint32_t *__restrict__ dep_e = a.dep_in + (size_t)e * a.ntile * a.dcap;
+    uint32_t tbase = 0;
+    {
+        typedef __attribute__((address_space(3))) W lds_w;
+        tbase = (uint32_t)(size_t)(lds_w *)tab;
+    }
+    if (t < 32) misc[t] = 0;
+    {   // the table, once per call (LDS-direct loads; the global copy is followed by zeros: the padded tail comes along)
+        const int nchunk = ts_table_chunks(a.tlen, RS, OWN, WB);
+        const char *srct = reinterpret_cast<const char *>(table_g) + lane * 16;
+        for (int c = wave; c < nchunk; c += FU_WAVES) {
+            const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tbase + (uint32_t)c * 1024u));
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(srct + c * 1024) : "memory");
+        }
+    }
+    const double beta = a.beta[e];
+    auto frame_site = [&](int i) -> int {
+        if (i < -1 || i > nfr) return -1;
+        int s = x0 + i;
+        if (BC == 1) { s %= L; if (s < 0) s += L; return s; }
+        return (s < 0 || s >= L) ? -1 : s;
+    };
+    const int ncell = (TS + 2) * K;
+    for (int c = t; c < ncell; c += FU_THREADS) {              // the frame's cells (+1 site either side) as the call finds them
+        const int s = frame_site(c / K - 1);
+        const uint32_t v = cell_e[(unsigned)max(s, 0) * (unsigned)K + (unsigned)(c % K)];
+        cellL[c] = s >= 0 ? v : CELL_EMPTY;
+        if (!K1) cellN[c] = CELL_EMPTY;
+    }
+#pragma unroll
+    for (int r = 0; r < NOLD; ++r) {                           // and its field
+        const int xi = r * FU_THREADS + t;
+        if (xi < TS) {
+            const int s = xi < nfr ? frame_site(xi) : -1;
+            WS o = ws_e[(unsigned)max(s, 0)];
+            if (s < 0) { o.x = 0; o.y = 0; }
+            fieldW[xi] = o.x; fieldS[xi] = o.y;
+        }
+    }
+    for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;
+    // buckets (= tiles) whose deposits can reach the frame: one run of nbk buckets from b0 that may wrap around the torus
+    int b0 = 0, nbk = 0;
+    if (BC == 0) {
+        b0 = max(0, x0c - Rt - 1) / OWN;
+        nbk = min(L - 1, x1c + Rt + 1) / OWN - b0 + 1;
+    } else {
+        const int lo = x0 - Rt - 1, hi = x0 + TS - 1 + Rt + 1;
+        if (hi - lo + 1 >= L) { b0 = 0; nbk = a.ntile; }
+        else {
+            const int lom = ((lo % L) + L) % L, him = ((hi % L) + L) % L;
+            const int blo = lom / OWN, bhi = him / OWN;
+            b0 = blo;
+            nbk = (lom <= him) ? bhi - blo + 1 : (a.ntile - blo) + bhi + 1;
+            if (nbk > a.ntile) { b0 = 0; nbk = a.ntile; }
+        }
+    }
+    const bool wall = BC == 0 && ((x0c + 1 <= Rt) || (L - x1c <= Rt));
+    const bool mirror_ok = 2 * Rt + TS + OWN + 4 < L;
+    const int sub = lane >> 4, slot = lane & (NSLOT - 1);
+    const uint32_t tlen8 = (uint32_t)a.tlen << SH, L8 = (uint32_t)L << SH;
+    uint32_t x8[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        int s = x0 + r * 64 + lane;
+        if (BC == 1) { s %= L; if (s < 0) s += L; } else s = min(max(s, 0), L - 1);
+        x8[r] = ((uint32_t)s + TS_BIAS) << SH;
+    }
+    // neighbours whose boundary cells this tile reads (-1: a wall)
+    const int nb_l = tile > 0 ? tile - 1 : (BC == 1 ? a.ntile - 1 : -1), nb_r = tile + 1 < a.ntile ? tile + 1 : (BC == 1 ? 0 : -1);
+    const size_t rec_e = (size_t)e * a.ntile;                  // records of this ensemble
+    const int null_site = x0c;
+    const uint32_t tb = tbase;
+    uint32_t *dep_o = a.dep_out + ((size_t)e * a.ntile + tile) * a.dcap;
+    uint32_t *cell_o = a.cell_out + (size_t)e * L * K;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's table chunks have landed
+    __syncthreads();
+
+#ifdef APS_LOOP_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t0;
+#define TLSTAMP(k) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t1_ - st_t0; st_t0 = t1_; }
+#else
+#define TLSTAMP(k)
+#endif
+    for (int it = 0; it < la.nsteps; ++it) {
+        const unsigned long long step = la.step0 + (unsigned long long)it;
+        const uint32_t tag_in = la.tag0 + (uint32_t)it, tag_out = tag_in + 1u;
+        const bool first = it == 0, last = it + 1 == la.nsteps;
+        const unsigned long long *rec_in = la.xrec + ((size_t)((it + 1) & 1) * a.E * a.ntile + rec_e) * la.rec;
+        unsigned long long *rec_out = la.xrec + ((size_t)(it & 1) * a.E * a.ntile + rec_e + tile) * la.rec;
+        int *dcount = misc + (it & 1), *pcount = misc + 2 + (it & 1);
+        bool gave_up = false;
+        // one bounded wait: every active lane re-reads its granule until it carries this step's tag
+        auto wait_granule = [&](const unsigned long long *p, bool active) -> uint32_t {
+            unsigned long long x = 0, t_w = 0;
+            for (unsigned spins = 0;; ++spins) {
+                if (active) x = tl_load_granule(p);
+                if (!__ballot(active && (uint32_t)(x >> 32) != tag_in)) break;
+#ifdef APS_LOOP_STAMPS
+                st_acc[7] += 1;
+#endif
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 63u) == 63u) {
+                    const bool other = __hip_atomic_load((tl_gu32 *)la.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (!t_w) t_w = now;
+                    if (other || now - t_w > la.timeout_ticks) {
+                        if (!other && lane == 0) {
+                            __hip_atomic_store((tl_gu32 *)la.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(la.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+#ifdef APS_LOOP_DEBUG
+                        if (!other) {                         // who waits for what: first missing lane reports
+                            const unsigned long long miss = __ballot(active && (uint32_t)(x >> 32) != tag_in);
+                            if (miss && lane == __builtin_ctzll(miss) && tile < 4096) {
+                                unsigned long long *o = a.rare->stamps + (size_t)tile * 8;
+                                o[0] = 0xDEAD; o[1] = (unsigned long long)it; o[2] = (unsigned long long)wave; o[3] = (unsigned long long)(p - la.xrec);
+                                o[4] = x; o[5] = tag_in; o[6] = miss; o[7] = (unsigned long long)la.rec;
+                            }
+                        }
+#endif
+                        gave_up = true;
+                        break;
+                    }
+                }
+            }
+            return (uint32_t)x;
+        };
+        // ------------------------------------------------------------ 0  the neighbours' boundary cells (three sites either side)
+        if (!first && wave == FU_WAVES - 1) {
+            const int side = lane >> 5, i = lane & 31;           // lanes 0..3K-1: left neighbour's LAST three sites; 32..: right neighbour's FIRST three
+            const int nb = side ? nb_r : nb_l;
+            const bool act = i < 3 * K && nb >= 0;
+            const uint32_t v = wait_granule(rec_in + (size_t)max(nb, 0) * la.rec + la.drec + (side ? 0 : 3 * K) + min(i, 3 * K - 1), act);
+            if (act && !gave_up) cellL[(side ? (own_n + 3) * K : 0) + i] = v;
+        }
+        // ------------------------------------------------------------ 1  deposits of the previous step -> W, S of the frame
+        W accP[RS], accM[RS], accF[RS], accWi[RS], accSi[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0;
+        int nP = 0, nM = 0, nF = 0, nI = 0;
+        const uint4 *segP4 = reinterpret_cast<const uint4 *>(segP), *segM4 = reinterpret_cast<const uint4 *>(segM),
+                    *segF4 = reinterpret_cast<const uint4 *>(segF), *segI4 = reinterpret_cast<const uint4 *>(segI);
+        auto flush = [&]() {
+            if (lane < 8) {
+                const uint32_t pad = DEP_NULL | ((uint32_t)null_site + TS_BIAS);
+                segP[nP + lane] = pad; segM[nM + lane] = pad; segF[nF + lane] = pad; segI[nI + lane] = DEP_NULL | ((uint32_t)x0c + TS_BIAS);
+            }
+#define TL_SWEEP(SEG4, N, MODE, ACC) { \
+            uint4 q = SEG4[0]; \
+            _Pragma("unroll 1") for (int i = 0; i < ((N) + 3) >> 2; ++i) { \
+                const uint4 qn = SEG4[i + 1]; \
+                if (BC == 1) ts_group<1, TAB_LDS, RS, MODE, F32>(q, x8, tb, table_g, tlen8, L8, ACC); \
+                else ts_group<0, TAB_LDS, RS, MODE, F32>(q, x8, tb, table_g, tlen8, L8, ACC); \
+                q = qn; } }
+            TL_SWEEP(segP4, nP, 0, accP)
+            TL_SWEEP(segM4, nM, 0, accM)
+            TL_SWEEP(segF4, nF, 1, accF)
+#undef TL_SWEEP
+#pragma unroll 1
+            for (int i = 0; i < (nI + 3) >> 2; ++i) ts_image_group<TAB_LDS, RS, F32>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
+            nP = nM = nF = nI = 0;
+        };
+#define TL_PUT(SEGX, NX, COND, WORD) { const unsigned long long m_ = __ballot(COND); \
+            if (COND) SEGX[NX + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u))] = (WORD); \
+            NX += __popcll(m_); }
+#define TL_FULL() (nP + 64 > SEG - 4 || nM + 64 > SEG - 4 || nF + 64 > SEG - 4 || nI + 64 > SEG - 4)
+        // 16 slots of each of the wave's four buckets per round: the valid ones go into the wave's segments by class.  Near a
+        // reflecting wall the image of a deposit is the same deposit at the mirrored site (pass 1; small boxes: image
+        // segment).  One more round after the last group (`drain`) sweeps what is left -- the sweep exists once in the code.
+        const int ngroups = (nbk + GB - 1) / GB;
+        const int npass = (wall && mirror_ok) ? 2 : 1;
+#pragma unroll 1
+        for (int j = 0; j <= ngroups && !gave_up; ++j) {
+            const bool drain = j == ngroups;
+            const int bi = j * GB + sub * FU_WAVES + wave;
+            const bool ok = !drain && bi < nbk;
+            int b = b0 + (ok ? bi : 0);
+            if (b >= a.ntile) b -= a.ntile;
+            uint32_t cnt = 0u;
+            if (first) { cnt = min(dcnt_e[(unsigned)b], (uint32_t)a.dcap); if (!ok) cnt = 0u; }   // the lists the previous launch left in the plain arrays
+            const unsigned long long *rb = rec_in + (size_t)b * la.rec;                             // else: the records of the previous iteration
+            bool active = ok;
+#pragma unroll 1
+            for (int page = 0;; ++page) {                      // a page of 16 slots per bucket at a time
+                uint32_t en = DEP_NULL;
+                bool valid = false, more = false;
+                if (first) {
+                    const uint32_t k0 = (uint32_t)page * NSLOT;
+                    en = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + slot, (uint32_t)a.dcap - 1u)];
+                    valid = k0 + slot < cnt; more = k0 + NSLOT < cnt;
+                } else if (__ballot(active)) {
+                    en = wait_granule(rb + min(page * NSLOT + slot, la.drec - 1), active);
+                    if (gave_up) break;
+                    valid = active && en != DEP_NULL;
+                    // a bucket has another page iff the last slot of this one is taken
+                    const unsigned long long mv = __ballot(valid);
+                    more = active && ((mv >> (sub * 16 + 15)) & 1ull) && (page + 1) * NSLOT < la.drec;
+                }
+                const uint32_t en_ = en + TS_BIAS;
+                const int dp = (int)(en & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2;
+                const bool img_l = valid && wall && (x0c + dp + 1 <= Rt), img_r = valid && wall && (2 * L - 1 - x1c - dp <= Rt);
+                const bool cP = cw != 0 && cw == cs, cM = cw != 0 && cw != cs, cF = cw == 0;
+                const bool im = img_l || img_r;
+                const bool pl = valid && (mirror_ok || !im);
+                const uint32_t mir = (en_ & ~POS_MASK) | (uint32_t)((int)TS_BIAS + (img_l ? -1 - dp : 2 * L - 1 - dp));
+#pragma unroll 1
+                for (int pass = 0; pass < npass; ++pass) {
+                    if (drain || TL_FULL()) flush();
+                    const bool c_ = pass ? im : pl;
+                    const uint32_t w_ = pass ? mir : en_;
+                    TL_PUT(segP, nP, (c_ && cP), w_) TL_PUT(segM, nM, (c_ && cM), w_) TL_PUT(segF, nF, (c_ && cF), w_)
+                    if (wall && !mirror_ok) TL_PUT(segI, nI, (valid && im), en_)
+                }
+                active = more;
+                if (!__ballot(active)) break;
+            }
+        }
+#undef TL_FULL
+#undef TL_PUT
+        if (!gave_up) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {                     // W = P + M, S = P - M + F (+ the image deposits), exact on the weight grid
+                const W dw = (accP[r] + accM[r]) + accWi[r], ds = ((accP[r] - accM[r]) + accF[r]) + accSi[r];
+                if (dw != 0) tl_lds_add(&fieldW[r * 64 + lane], dw);
+                if (ds != 0) tl_lds_add(&fieldS[r * 64 + lane], ds);
+            }
+        } else if (lane == 0) misc[TL_ABORT] = 1;
+        TLSTAMP(0)
+        __syncthreads();                                       // B: field and cells of the frame complete
+        TLSTAMP(1)
+        if (misc[TL_ABORT]) return;                            // uniform: some wait ran out (here or in another workgroup)
+        // ------------------------------------------------------------ 2  occupancy, the frame's particles
+        for (int i = t; i < TS + 2; i += FU_THREADS) {
+            int n = 0;
+            for (int k = 0; k < K; ++k) n += cellL[i * K + k] != CELL_EMPTY;
+            occL[i] = (uint8_t)n;
+        }
+        for (int c0 = 0; c0 < ncell; c0 += FU_THREADS) {       // uniform trip count
+            const int c = c0 + t;
+            const int pos = K1 ? c - 1 : c / K - 1, k = K1 ? 0 : c - (pos + 1) * K;
+            const uint32_t cw = c < ncell ? cellL[c] : CELL_EMPTY;
+            const bool occ = cw != CELL_EMPTY && pos >= 0 && pos < nfr;
+            const unsigned long long mm = __ballot(occ);
+            const int cnt_u = __popcll(mm);
+            int base = 0;
+            if (lane == 0 && cnt_u) base = atomicAdd(pcount, cnt_u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (occ) plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)pos | ((uint32_t)k << 16), cw);
+        }
+        __syncthreads();                                       // C
+        TLSTAMP(2)
+        // ------------------------------------------------------------ 2b proposals, a lane per particle
+        {
+            const Model M = *a.model;                          // uniform address: scalar loads, only now
+            const int n_part = *pcount;
+            for (int j = t; j < n_part; j += FU_THREADS) {
+                const uint2 pc = plist[j];
+                uint32_t x[4];
+                philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
+                const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16);
+                const int s = frame_site(pos);
+                const bool anch = a.anchor ? a.anchor[s] != 0 : false;
+                propL[pos * K + k] = decide_proposal(M, anch, s, (pc.y & CELL_PLUS) ? 1 : -1, (pc.y & CELL_BOUND) != 0,
+                                                     clip_field((double)fieldS[pos], (double)fieldW[pos]), beta, occL[pos + 1], occL[pos], occL[pos + 2], x);
+            }
+        }
+        __syncthreads();                                       // D
+        TLSTAMP(3)
+        // ------------------------------------------------------------ 3 + 4  exclusion, new cells of the owned sites, deposits
+        auto rank_at = [&](int j, uint32_t id) -> int {
+            int n = 0;
+            for (int k = 0; k < K; ++k) {
+                const uint32_t cl_ = cellL[j * K + k], cr_ = cellL[(j + 2) * K + k];
+                const int el = propL[(j - 1) * K + k] & 7, er = propL[(j + 1) * K + k] & 7;
+                n += (cl_ != CELL_EMPTY && (el == EV_RIGHT || el == EV_FWD) && (cl_ & CELL_ID) < id);
+                n += (cr_ != CELL_EMPTY && er == EV_LEFT && (cr_ & CELL_ID) < id);
+            }
+            return n;
+        };
+        auto cap_at = [&](int j) -> int { const int c = K - (int)occL[j + 1]; return c < 1 ? 1 : (c > 32 ? 32 : c); };
+        auto put_deposit = [&](int kd, uint32_t d) { if (last) dep_o[kd] = d; else tl_store_granule(rec_out + kd, tag_out, d); };
+        uint32_t newc[NOLD];                                   // K = 1: the owned sites' cells after this step
+#pragma unroll
+        for (int r = 0; r < NOLD; ++r) {
+            newc[r] = CELL_EMPTY;
+            const int xi = r * FU_THREADS + t;
+            if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
+            const int s = frame_site(xi);
+            uint32_t *outN = cellN + (xi + 1) * K;
+            int n_out = 0;
+            auto emit = [&](uint32_t c) { if (K1) newc[r] = c; else outN[n_out] = c; ++n_out; };
+            for (int k = 0; k < K; ++k) {
+                uint32_t c = cellL[(xi + 1) * K + k];
+                if (c == CELL_EMPTY) continue;
+                const int ev = propL[xi * K + k] & 7, sgn = (c & CELL_PLUS) ? 1 : -1;
+                uint32_t d0 = 0, d1 = 0;
+                int nd = 0;
+                bool stays = true;
+                if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
+                    const int j = ev == EV_LEFT ? xi - 1 : xi + 1;
+                    if (rank_at(j, c & CELL_ID) < cap_at(j)) {
+                        stays = false;
+                        d0 = deposit(s, -1, -sgn); d1 = deposit(frame_site(j), 1, sgn); nd = 2;
+                    }
+                } else if (ev == EV_BIND) c |= CELL_BOUND;
+                else if (ev == EV_UNBIND) c &= ~CELL_BOUND;
+                else if (ev == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
+                // (EV_EXIT cannot be drawn: the host only takes this path when no particle can leave)
+                if (stays) emit(c);
+                if (nd) {
+                    const int kd = atomicAdd(dcount, nd);
+                    if (kd + nd <= a.dcap) { put_deposit(kd, d0); if (nd == 2) put_deposit(kd + 1, d1); }
+                }
+            }
+            const int cap = cap_at(xi);
+            for (int k = 0; k < K; ++k) {
+                const uint32_t cl_ = cellL[xi * K + k], cr_ = cellL[(xi + 2) * K + k];
+                const int el = propL[(xi - 1) * K + k] & 7, er = propL[(xi + 1) * K + k] & 7;
+                if (cl_ != CELL_EMPTY && (el == EV_RIGHT || el == EV_FWD) && rank_at(xi, cl_ & CELL_ID) < cap) emit(cl_);
+                if (cr_ != CELL_EMPTY && er == EV_LEFT && rank_at(xi, cr_ & CELL_ID) < cap) emit(cr_);
+            }
+            if (!K1) for (int k = n_out; k < K; ++k) outN[k] = CELL_EMPTY;
+        }
+        __syncthreads();                                       // E: nobody reads this step's cells and proposals any more
+        TLSTAMP(4)
+        // ------------------------------------------------------------ 5  hand over: new cells, this tile's record (or the plain arrays)
+        const int count = min(*dcount, a.dcap);
+#pragma unroll
+        for (int r = 0; r < NOLD; ++r) {
+            const int xi = r * FU_THREADS + t;
+            if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
+            const int io = xi - 2;
+#ifdef APS_LOOP_DEBUG
+            if (la.dbg) { la.dbg[((size_t)it * 3 + 1) * L + frame_site(xi)] = (uint32_t)occL[xi + 1] | ((uint32_t)propL[xi * K] << 8) | ((uint32_t)occL[xi] << 16) | ((uint32_t)occL[xi + 2] << 24);
+                          la.dbg[((size_t)it * 3 + 2) * L + frame_site(xi)] = cellL[(xi + 1) * K]; }
+#endif
+            for (int k = 0; k < K; ++k) {
+                const uint32_t c = K1 ? newc[r] : cellN[(xi + 1) * K + k];
+#ifdef APS_LOOP_DEBUG
+                if (la.dbg && k == 0) la.dbg[((size_t)it * 3 + 0) * L + frame_site(xi)] = c;
+#endif
+                cellL[(xi + 1) * K + k] = c;
+                if (last) cell_o[(unsigned)frame_site(xi) * (unsigned)K + (unsigned)k] = c;
+                else {
+                    if (io < 3) tl_store_granule(rec_out + la.drec + io * K + k, tag_out, c);
+                    if (io >= own_n - 3) tl_store_granule(rec_out + la.drec + 3 * K + (io - (own_n - 3)) * K + k, tag_out, c);
+                }
+            }
+            if (last) {
+                WS f; f.x = fieldW[xi]; f.y = fieldS[xi];
+                reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
+            }
+        }
+        if (!last && t < NSLOT) {                              // the rest of the record's last page: empty slots (at least one)
+            const int idx = count + t;
+            if (idx < (count / NSLOT + 1) * NSLOT && idx < la.drec) tl_store_granule(rec_out + idx, tag_out, DEP_NULL);
+        }
+        for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;
+        if (t == 0) {
+            misc[(it + 1) & 1] = 0; misc[2 + ((it + 1) & 1)] = 0;        // the next iteration's counters
+            if (last) {
+                a.dcnt_out[(size_t)e * a.ntile + tile] = (uint32_t)count;
+                if (tile == 0 && e == 0) a.stepw[a.par ^ 1] = la.step0 + (unsigned long long)la.nsteps;
+            }
+        }
+        // (no barrier here: the next iteration touches none of these words before its barrier B)
+        TLSTAMP(5)
+    }
+#ifdef APS_LOOP_STAMPS
+    if (t == 0 && tile < 4096 && e == 0) {
+        unsigned long long *o = a.rare->stamps + (size_t)tile * 8;
+        for (int k = 0; k < 6; ++k) o[k] = st_acc[k];
+        o[6] = __builtin_amdgcn_s_memtime() - st_begin; o[7] = st_acc[7];
+    }
+#endif
+}

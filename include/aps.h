@@ -227,6 +227,19 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *la
  * kernel by kernel. */
 int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps);
 
+/* Resident loop (TILES, one rank, weight table in LDS, local field, no exits, the whole grid of tiles resident on the device
+ * at once -- BASELINE config 2): aps_step then runs its steps inside ONE launch; every tile keeps its state on chip and
+ * exchanges only deposit lists and boundary cells with its neighbours between two steps.  Same bits as one launch per step
+ * (replaces the loop of ParticleSystem.run, PARTICLE_solver_CLASS.py:511-516, like aps_step itself).  on = 0 keeps a handle
+ * on one launch per step; default 1 (used when eligible).  aps_loop_info: steps of the last aps_step call taken inside the
+ * loop; state 1 usable, 0 not eligible, -1 a call gave up (the steps were repeated the ordinary way; not tried again),
+ * -2 not looked at yet; `why` receives the reason when the loop is not used. */
+int aps_set_resident_loop(aps_handle *h, int32_t on);
+int aps_loop_info(aps_handle *h, int64_t *loop_steps, int32_t *state, char *why, int32_t why_len);
+/* Measurement: aps_step(nsteps) with HIP start/stop events attached to the resident loop's own dispatch; returns that
+ * launch's duration and the steps it took (0 / 0.0 when the call did not use the loop). */
+int aps_step_loop_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *loop_steps);
+
 /* Measurement: bytes read + bytes written per second of a plain 16-byte-per-lane copy kernel over nbytes (>= 1 MiB; use
  * >= 1 GiB to get past the caches) on the handle's device -- the streaming ceiling of THIS box, quoted beside the spec. */
 int aps_copy_bandwidth(aps_handle *h, int64_t nbytes, int32_t reps, double *gbytes_per_s);

@@ -1,0 +1,38 @@
+"""Diagnostic: build the library with -DAPS_LOOP_STAMPS into /tmp and print where a workgroup of the resident loop
+(csrc/tile_loop.hpp) spends an iteration.  Usage (GPU box): python tools/stamps_loop.py [steps] [-DAPS_...]"""
+import ctypes as C, importlib, os, subprocess, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "hydrodynamic-limits-of-active-particle-systems-with-mean-field-interactions_amd"
+extra = sys.argv[1:]
+steps = 201
+if extra and not extra[0].startswith("-"):
+    steps, extra = int(extra[0]) | 1, extra[1:]
+lib = f"/tmp/libaps_stamps_loop_{'_'.join(x.strip('-D') for x in extra)}.so"
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DAPS_LOOP_STAMPS",
+                "-DAPS_DEV_RS=" + os.environ.get("APS_TS_R", "5"), *extra, "-I", os.path.join(ROOT, "include"), "-o", lib,
+                os.path.join(ROOT, PKG, "csrc", "aps_hip.hip")], check=True)
+capi = importlib.import_module(PKG + ".capi")
+capi.LIB_PATH = lib
+import bench
+w = dict(bench.WORK)
+h = bench.make_handle(capi, w, method="tiles")
+h.set_state(*bench.initial_state(w))
+h.step(201)
+t0 = time.perf_counter(); h.step(steps); dt = time.perf_counter() - t0
+print("loop_info", h.loop_info(), f"{dt / steps * 1e6:.2f} us per step (wall, stamps build)")
+buf = np.zeros(8 * 4096, dtype=np.uint64)
+fn = h.lib.aps_debug_stamps
+fn.restype = C.c_int
+fn(h._h, buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf)))
+st = buf.reshape(-1, 8)
+idx = np.flatnonzero(st[:, 6] > 0)
+st = st[idx].astype(float) / steps
+print("workgroups", len(st), "; cycles per iteration (s_memtime, 100 MHz? see total vs wall), wave 0 of each workgroup")
+for k, name in ((0, "wait + intake + sweep"), (1, "barrier B"), (2, "occupancy + list (C)"), (3, "proposals (D)"), (4, "exclusion (E)"),
+                (5, "hand over"), (6, "total"), (7, "failed polls")):
+    print(f"  {name:24s} mean {st[:, k].mean():9.1f}   median {np.median(st[:, k]):9.1f}   min {st[:, k].min():9.1f}   max {st[:, k].max():9.1f}")
+worst = np.argsort(-st[:, 0])[:8]
+print("  longest wait+sweep: tiles", idx[worst], st[worst, 0].round(0))
+h.close()
