@@ -55,7 +55,7 @@ LDS_CYCLES_PER_64_PAIRS = 5.0  # measured (PMC 4.93): 4.5 per table gather (2.0 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes, per workload
 
 
-def measured_traffic_bytes(workload, kernel):
+def measured_traffic_bytes(workload, kernel, steps_per_launch=1):
     """HBM-side bytes per launch of `kernel` in `workload` from the committed rocprofv3 --pmc passes of this round's
     binary (bench.py cannot collect PMC itself; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     streaming reads is NOT applied: these kernels read 4-16 bytes per lane).  None when no pass was recorded for this
@@ -63,7 +63,7 @@ def measured_traffic_bytes(workload, kernel):
     try:
         with open(TRAFFIC_FILE) as fh:
             d = json.load(fh)["workloads"][workload][kernel]
-        return (d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0
+        return (d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0 / d.get("steps_per_dispatch", 1) * steps_per_launch
     except Exception:
         return None
 
@@ -571,13 +571,13 @@ def main():
             else:
                 limiter = "valu/lds issue of the deposit sweep (f64 fma + LDS table gather per deposit x 64-site row)"
             roof = {"bound": "hbm", "bound_measured": limiter, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(args.workload, dom),
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(args.workload, dom, max(loop_steps, 1)),
                     "hbm_copy_GBps": hbm_copy, "frac_of_copy": achieved / hbm_copy,
                     "avg_launch_us": kern[dom] * 1e6, "algorithmic_bytes_per_launch": algo[dom],
                     "timing": "HIP events around each launch" if bracketed else "HIP start/stop events attached to each dispatch",
                     "per_kernel": {k: {"avg_launch_us": kern[k] * 1e6, "algorithmic_bytes_per_launch": algo[k],
                                        "achieved_GBps": algo[k] / kern[k] / 1e9,
-                                       "traffic": measured_traffic_bytes(args.workload, k)} for k in kern},
+                                       "traffic": measured_traffic_bytes(args.workload, k, loop_steps if k == "tile_loop" else 1)} for k in kern},
                     "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step": us_step,
                                    "achieved_GBps": step_bytes / (us_step * 1e-6) / 1e9,
                                    "frac": step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS},

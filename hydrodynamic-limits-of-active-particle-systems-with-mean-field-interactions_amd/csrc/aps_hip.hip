@@ -1394,7 +1394,7 @@ struct aps_handle {
     // resident loop (tile_loop): many steps per launch while every tile of the grid is resident at once
     unsigned long long *d_xrec = nullptr;                      // [2][E][ntile][loop_rec] exchange records (8-byte granules)
     unsigned *d_abort = nullptr, *h_abort = nullptr, *h_abort_dev = nullptr;   // "a wait ran out": device word, host-mapped word and its device address
-    int loop_rec = 0, loop_drec = 0;
+    int loop_rec = 0, loop_drec = 0, loop_seg = 0;
     int loop_state = -2;                                       // -2 not looked at yet, -1 gave up once (never again), 0 not eligible, 1 usable
     int loop_wanted = 1;                                       // aps_set_resident_loop
     uint32_t loop_tag = 0;                                     // tags handed out so far
@@ -1825,8 +1825,22 @@ void ts_choose_geometry(aps_handle *h) {
     if ((double)(((int64_t)L + 507) / 508) * h->E > 3.0 * 256.0)      // even the largest frame leaves more than 3 per CU
         h->ts_RS = !h->f32 ? 4 : 7;   // measured (r02 geometry sweeps): binary64 config 4 RS 3..8 = 67, 59.5, 65, 62, 73, 74 us, config 5 RS 4..6 = 550, 607, 544;
                                      // 32-bit field config 4 RS 4..8 = 56, 52, 50, 46.7, 47.4 us, config 5 = 428, 345, 347, 312, 371
-    if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) h->ts_RS = r; }
-    h->ts_own = 64 * h->ts_RS - 4;
+    // One system whose tiles can all stay resident (the resident loop, tile_loop.hpp: every workgroup keeps its tile for the
+    // whole call, so the busiest CU sets the pace): exactly two workgroups on every CU instead of three on some and two on
+    // the others (config 2: 512 tiles of 391 sites, 12.8 us per step against 13.3 with 633 tiles of 316; one launch per
+    // step is indifferent: 14.65 against 14.55)
+    int own_even = 0;
+    if (h->world == 1 && h->model.field_mode && !(h->model.immobilize && h->model.k_exit > 0.0) && 3 * h->p.K <= 32) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->p.device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        const int64_t target = 2LL * cus / std::max(h->E, 1);
+        if (target >= 1) {
+            const int own = (int)((L + target - 1) / target), rs = (own + 4 + 63) / 64;
+            if (own >= 124 && rs <= 8) { h->ts_RS = rs; own_even = own; }
+        }
+    }
+    if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) { h->ts_RS = r; own_even = 0; } }
+    h->ts_own = own_even ? own_even : 64 * h->ts_RS - 4;
     if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
@@ -1945,19 +1959,25 @@ int loop_prepare(aps_handle *h) {
 #ifdef APS_STAMPS
     return no("diagnostic build");
 #endif
-    const TlLds lay = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h));
-    if (lay.total > 160 * 1024) return no("tile does not fit LDS with its state resident");
     const void *fn = tl_kernel(h);
     if (!fn) return no("no kernel for this frame");
-    if (lay.total > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total) != hipSuccess) { (void)hipGetLastError(); return no("hipFuncSetAttribute failed"); }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FU_THREADS, lay.total) != hipSuccess) { (void)hipGetLastError(); return no("occupancy query failed"); }
     // The API can promise one block more than the hardware admits (MI355X_MICROARCH.md, residency).  Measured here: with
     // 54 040 B of LDS per block the API said 3 per CU and only 2 were ever resident -- LDS is handed out in 128 granules of
     // 1 280 B (160 KB / 128), so a block takes ceil(bytes / 1280) of them; and at most 8 blocks of 256 threads per CU.
-    const int lds_granules = (int)((lay.total + 1279) / 1280);
-    per_cu = std::min(std::min(per_cu, 8), 128 / std::max(lds_granules, 1));
-    if ((int64_t)h->ts_ntile * h->E > (int64_t)per_cu * h->num_cu) return no("more tiles than the device keeps resident at once");
+    // Deposit segments: the longest (of 256, 192, 128, 88 entries) that still lets the whole grid be resident.
+    const int64_t need_per_cu = ((int64_t)h->ts_ntile * h->E + h->num_cu - 1) / h->num_cu;
+    h->loop_seg = 0;
+    size_t lds_total = 0;
+    for (int seg : {256, 192, 128, TL_SEG_MIN}) {
+        const TlLds lay = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h), seg);
+        if (lay.total > 160 * 1024) continue;
+        if (128 / (int)((lay.total + 1279) / 1280) >= need_per_cu) { h->loop_seg = seg; lds_total = lay.total; break; }
+    }
+    if (!h->loop_seg) return no("more tiles than the device keeps resident at once (LDS)");
+    if (lds_total > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total) != hipSuccess) { (void)hipGetLastError(); return no("hipFuncSetAttribute failed"); }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FU_THREADS, lds_total) != hipSuccess) { (void)hipGetLastError(); return no("occupancy query failed"); }
+    if (need_per_cu > std::min(per_cu, 8)) return no("more tiles than the device keeps resident at once");
     h->loop_drec = (h->ts_dcap / 16 + 1) * 16;
     h->loop_rec = (h->loop_drec + 6 * h->p.K + 15) / 16 * 16;
     int rc;
@@ -1983,7 +2003,7 @@ int launch_tile_loop(aps_handle *h, int64_t n) {
     }
     la.tag0 = h->loop_tag;
     h->loop_tag += (uint32_t)n + 1u;
-    la.rec = h->loop_rec; la.drec = h->loop_drec; la.xrec = h->d_xrec;
+    la.rec = h->loop_rec; la.drec = h->loop_drec; la.xrec = h->d_xrec; la.seg = h->loop_seg;
     la.abort_dev = h->d_abort; la.abort_host = h->h_abort_dev;
     la.timeout_ticks = 5000000ull;                                             // 50 ms of the 100 MHz clock per wait (a hand-off takes microseconds)
     if (const char *env = std::getenv("APS_LOOP_TIMEOUT_MS")) la.timeout_ticks = (unsigned long long)std::max(1, std::atoi(env)) * 100000ull;
@@ -1996,7 +2016,7 @@ int launch_tile_loop(aps_handle *h, int64_t n) {
 #endif
     if (std::getenv("APS_LOOP_TEST_ABORT")) HIP_TRY(h, hipMemsetAsync(h->d_abort, 1, 4, h->stream));   // tests: the call gives up at once
     const void *fn = tl_kernel(h);
-    const size_t lds = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total;
+    const size_t lds = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h), h->loop_seg).total;
     const void *table_ptr = h->f32 ? (const void *)h->d_table_i : (const void *)h->d_table;
     void *args[] = {(void *)&la, (void *)&table_ptr};
     const dim3 grid((unsigned)h->ts_ntile, (unsigned)h->E), block(FU_THREADS);
@@ -2724,7 +2744,7 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     h->last_graph_steps = h->last_single_steps = h->last_loop_steps = 0;
     int64_t loop_min = 3;                                        // below that a call is not worth the loop's set-up
     if (const char *env = std::getenv("APS_LOOP_MIN")) loop_min = std::max(1, std::atoi(env));
-    if (is_tiles(h) && h->world == 1 && h->loop_wanted && nsteps >= loop_min && h->loop_state != 0 && h->loop_state != -1) {
+    if (is_tiles(h) && h->world == 1 && !h->comm && h->loop_wanted && nsteps >= loop_min && h->loop_state != 0 && h->loop_state != -1) {
         const char *env = std::getenv("APS_TILE_LOOP");
         if (!(env && env[0] == '0')) {
             if ((rc = loop_prepare(h))) return rc;

@@ -21,7 +21,9 @@
 // the same bits either way: the arithmetic and the random numbers are tile_step's.
 #pragma once
 
-constexpr int TL_SEG = 88;                 // entries per deposit segment of a wave (config 2: 3 workgroups per CU need <= 42 LDS granules of 1280 B each)
+constexpr int TL_SEG_MIN = 88;             // entries per deposit segment of a wave at least (three workgroups per CU at config 2's 37 KB table: <= 42 LDS granules of 1280 B);
+                                           // the host takes up to 256 when the residency the grid needs leaves room (fewer, larger sweeps)
+constexpr int TL_NG = 2;                   // bucket groups whose first page a wave asks for ahead of time (config 2 has two)
 constexpr int TL_ABORT = 31;               // misc word: this workgroup leaves (a wait ran out, here or elsewhere)
 
 struct LoopArgs {
@@ -30,6 +32,7 @@ struct LoopArgs {
     int nsteps;                            // odd
     uint32_t tag0;                         // the records written in iteration s carry the tag tag0 + s + 1 (never 0, never reused)
     int rec, drec;                         // granules per record; deposit slots of a record (a multiple of 16 above dcap)
+    int seg;                               // entries per deposit segment of a wave (a multiple of 4)
     unsigned long long *xrec;              // [2][E][ntile][rec] {tag << 32 | word}
     unsigned *abort_dev, *abort_host;      // raised by a workgroup whose wait ran out
     unsigned long long timeout_ticks;      // of the 100 MHz clock
@@ -39,12 +42,12 @@ struct LoopArgs {
 };
 
 struct TlLds { size_t seg, cells, cells2, props, occ, misc, plist, fw, fs, tab, total; };
-__host__ __device__ inline TlLds tl_lds_layout(int tlen, int RS, int own, int K, int wbytes) {
+__host__ __device__ inline TlLds tl_lds_layout(int tlen, int RS, int own, int K, int wbytes, int seg) {
     TlLds l;
     const size_t TS = 64 * (size_t)RS, ncell = (TS + 2) * K;
     auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     l.seg = 0;
-    l.cells = l.seg + (size_t)FU_WAVES * 4 * (TL_SEG + 4) * sizeof(uint32_t);
+    l.cells = l.seg + (size_t)FU_WAVES * 4 * (seg + 4) * sizeof(uint32_t);
     l.cells2 = up(l.cells + ncell * 4, 8);
     l.props = up(l.cells2 + (K == 1 ? 0 : ncell * 4), 8);
     l.occ = up(l.props + TS * K, 8);
@@ -71,7 +74,7 @@ __device__ __forceinline__ void tl_lds_add(double *p, double v) { unsafeAtomicAd
 __device__ __forceinline__ void tl_lds_add(int *p, int v) { atomicAdd(p, v); }
 
 template <int BC, int RS, bool K1, bool F32>
-__global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
+__global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
     using W = typename TsField<F32>::w_t;
     using WS = typename TsField<F32>::ws_t;
     constexpr int SH = TsField<F32>::SH, WB = (int)sizeof(W);
@@ -79,17 +82,18 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
     const TileArgs &a = la.a;
     const W *__restrict__ table_g = reinterpret_cast<const W *>(table_v);
     constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS, NCR = (TS + 2 + FU_THREADS - 1) / FU_THREADS;
-    constexpr int SEG = TL_SEG, NSLOT = 16, GB = FU_WAVES * 4;
+    constexpr int NSLOT = 16, GB = FU_WAVES * 4;
+    const int SEG = la.seg;
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
-    const TlLds lay = tl_lds_layout(a.tlen, RS, OWN, K, WB);
+    const TlLds lay = tl_lds_layout(a.tlen, RS, OWN, K, WB, la.seg);
     char *lds_c = reinterpret_cast<char *>(lds);
     uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
     uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
     uint32_t *cellN = reinterpret_cast<uint32_t *>(lds_c + lay.cells2);      // K > 1: the cells after this step
     uint8_t *propL = reinterpret_cast<uint8_t *>(lds_c + lay.props);         // [TS K]
     uint8_t *occL = reinterpret_cast<uint8_t *>(lds_c + lay.occ);            // [TS + 2]
-    int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // 0/1 deposits of this tile (by iteration parity), 2/3 particles on the frame
+    int *misc = reinterpret_cast<int *>(lds_c + lay.misc);                   // by iteration parity: 0/1 deposits of this tile, 2/3 particles of the owned sites, 4/5 of the halo sites
     uint2 *plist = reinterpret_cast<uint2 *>(lds_c + lay.plist);
     W *fieldW = reinterpret_cast<W *>(lds_c + lay.fw), *fieldS = reinterpret_cast<W *>(lds_c + lay.fs);   // [TS] each: the frame's field, kept across the steps
     W *tab = reinterpret_cast<W *>(lds_c + lay.tab);
@@ -181,8 +185,32 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
     const uint32_t tb = tbase;
     uint32_t *dep_o = a.dep_out + ((size_t)e * a.ntile + tile) * a.dcap;
     uint32_t *cell_o = a.cell_out + (size_t)e * L * K;
+    const int ngroups = (nbk + GB - 1) / GB;
+    const int npass = (wall && mirror_ok) ? 2 : 1;
+    // the frame's particles {pos | k << 16, cell} pooled into one list, and the occupancy of the frame sites: once from
+    // the staged cells here, afterwards kept up to date by the hand-over of every iteration
+    auto append = [&](bool occ, int pos, int k, uint32_t cw, int *counter) {
+        const unsigned long long mm = __ballot(occ);
+        const int cnt_u = __popcll(mm);
+        int base = 0;
+        if (lane == 0 && cnt_u) base = atomicAdd(counter, cnt_u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (occ) plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)pos | ((uint32_t)k << 16), cw);
+    };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's table chunks have landed
-    __syncthreads();
+    __syncthreads();                                           // cells staged
+    for (int i = t; i < TS + 2; i += FU_THREADS) {
+        int n = 0;
+        for (int k = 0; k < K; ++k) n += cellL[i * K + k] != CELL_EMPTY;
+        occL[i] = (uint8_t)n;
+    }
+    for (int c0 = 0; c0 < ncell; c0 += FU_THREADS) {           // uniform trip count
+        const int c = c0 + t;
+        const int pos = K1 ? c - 1 : c / K - 1, k = K1 ? 0 : c - (pos + 1) * K;
+        const uint32_t cw = c < ncell ? cellL[c] : CELL_EMPTY;
+        append(cw != CELL_EMPTY && pos >= 0 && pos < nfr, pos, k, cw, misc + 2);
+    }
+    __syncthreads();                                           // F of "iteration -1"
 
 #ifdef APS_LOOP_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime();
@@ -191,6 +219,21 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
 #else
 #define TLSTAMP(k)
 #endif
+    // what this wave asked for at the end of the previous iteration (in flight across barrier F and the random numbers):
+    // page 0 of its buckets of the first TL_NG groups, and (last wave) the neighbours' boundary cells
+    unsigned long long xg[TL_NG], xh = 0;
+#pragma unroll
+    for (int g = 0; g < TL_NG; ++g) xg[g] = 0;
+    const int h_side = lane >> 5, h_i = lane & 31;             // lanes 0..3K-1: left neighbour's LAST three sites; 32..: right neighbour's FIRST three
+    const int h_nb = h_side ? nb_r : nb_l;
+    const bool h_act = wave == FU_WAVES - 1 && h_i < 3 * K && h_nb >= 0;
+    auto bucket_of = [&](int j, bool &ok) -> int {
+        const int bi = j * GB + sub * FU_WAVES + wave;
+        ok = j < ngroups && bi < nbk;
+        int b = b0 + (ok ? bi : 0);
+        if (b >= a.ntile) b -= a.ntile;
+        return b;
+    };
     for (int it = 0; it < la.nsteps; ++it) {
         const unsigned long long step = la.step0 + (unsigned long long)it;
         const uint32_t tag_in = la.tag0 + (uint32_t)it, tag_out = tag_in + 1u;
@@ -199,50 +242,76 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
         unsigned long long *rec_out = la.xrec + ((size_t)(it & 1) * a.E * a.ntile + rec_e + tile) * la.rec;
         int *dcount = misc + (it & 1), *pcount = misc + 2 + (it & 1);
         bool gave_up = false;
-        // one bounded wait: every active lane re-reads its granule until it carries this step's tag
+        // ------------------------------------------------------------ A  this thread's particle and its random numbers (while the records travel)
+        const int n0 = *pcount;                                // the owned sites' particles (first iteration: the whole frame's)
+        uint2 mine = make_uint2(0u, CELL_EMPTY);
+        uint32_t rx[4] = {0u, 0u, 0u, 0u};
+        if (t < n0) {
+            mine = plist[t];
+            philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, rx);
+        }
+        TLSTAMP(2)
+        // ------------------------------------------------------------ B  bounded waits: re-read until the granule carries this step's tag
+        auto spin_check = [&](unsigned &spins, unsigned long long &t_w) -> bool {     // true: give up
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) != 0u) return false;
+            const bool other = __hip_atomic_load((tl_gu32 *)la.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (!t_w) t_w = now;
+            if (!other && now - t_w <= la.timeout_ticks) return false;
+            if (!other && lane == 0) {
+                __hip_atomic_store((tl_gu32 *)la.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(la.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            gave_up = true;
+            return true;
+        };
         auto wait_granule = [&](const unsigned long long *p, bool active) -> uint32_t {
             unsigned long long x = 0, t_w = 0;
-            for (unsigned spins = 0;; ++spins) {
+            for (unsigned spins = 0;;) {
                 if (active) x = tl_load_granule(p);
                 if (!__ballot(active && (uint32_t)(x >> 32) != tag_in)) break;
-#ifdef APS_LOOP_STAMPS
-                st_acc[7] += 1;
-#endif
-                __builtin_amdgcn_s_sleep(1);
-                if ((spins & 63u) == 63u) {
-                    const bool other = __hip_atomic_load((tl_gu32 *)la.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                    if (!t_w) t_w = now;
-                    if (other || now - t_w > la.timeout_ticks) {
-                        if (!other && lane == 0) {
-                            __hip_atomic_store((tl_gu32 *)la.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(la.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        }
-#ifdef APS_LOOP_DEBUG
-                        if (!other) {                         // who waits for what: first missing lane reports
-                            const unsigned long long miss = __ballot(active && (uint32_t)(x >> 32) != tag_in);
-                            if (miss && lane == __builtin_ctzll(miss) && tile < 4096) {
-                                unsigned long long *o = a.rare->stamps + (size_t)tile * 8;
-                                o[0] = 0xDEAD; o[1] = (unsigned long long)it; o[2] = (unsigned long long)wave; o[3] = (unsigned long long)(p - la.xrec);
-                                o[4] = x; o[5] = tag_in; o[6] = miss; o[7] = (unsigned long long)la.rec;
-                            }
-                        }
-#endif
-                        gave_up = true;
-                        break;
-                    }
-                }
+                if (spin_check(spins, t_w)) break;
             }
             return (uint32_t)x;
         };
-        // ------------------------------------------------------------ 0  the neighbours' boundary cells (three sites either side)
-        if (!first && wave == FU_WAVES - 1) {
-            const int side = lane >> 5, i = lane & 31;           // lanes 0..3K-1: left neighbour's LAST three sites; 32..: right neighbour's FIRST three
-            const int nb = side ? nb_r : nb_l;
-            const bool act = i < 3 * K && nb >= 0;
-            const uint32_t v = wait_granule(rec_in + (size_t)max(nb, 0) * la.rec + la.drec + (side ? 0 : 3 * K) + min(i, 3 * K - 1), act);
-            if (act && !gave_up) cellL[(side ? (own_n + 3) * K : 0) + i] = v;
+        if (!first) {                                          // everything asked for ahead: one round trip when the neighbours are done
+            unsigned long long t_w = 0;
+            for (unsigned spins = 0;;) {
+                bool bad = false;
+#pragma unroll
+                for (int g = 0; g < TL_NG; ++g) {
+                    bool ok;
+                    const int b = bucket_of(g, ok);
+                    if (ok && (uint32_t)(xg[g] >> 32) != tag_in) {
+                        xg[g] = tl_load_granule(rec_in + (size_t)b * la.rec + slot);
+                        bad |= (uint32_t)(xg[g] >> 32) != tag_in;
+                    }
+                }
+                if (h_act && (uint32_t)(xh >> 32) != tag_in) {
+                    xh = tl_load_granule(rec_in + (size_t)h_nb * la.rec + la.drec + (h_side ? 0 : 3 * K) + h_i);
+                    bad |= (uint32_t)(xh >> 32) != tag_in;
+                }
+                if (!__ballot(bad)) break;
+                if (spin_check(spins, t_w)) break;
+            }
+            // the neighbours' boundary cells: frame positions -1, 0, 1 and own_n + 2 .. own_n + 4 -- occupancy, and the
+            // particles of the four halo sites join the list
+            if (wave == FU_WAVES - 1 && !gave_up) {
+                const uint32_t v = h_act ? (uint32_t)xh : CELL_EMPTY;
+                const int hs = h_i / K, hk = h_i - hs * K, pos = (h_side ? own_n + 2 : -1) + hs;
+                if (h_act) cellL[(h_side ? (own_n + 3) * K : 0) + h_i] = v;
+                // occupancy of the six sites: K consecutive lanes per site
+                const unsigned long long mo = __ballot(h_act && v != CELL_EMPTY);
+                if (h_i < 3 * K && hk == 0 && h_nb >= 0) occL[pos + 1] = (uint8_t)__popcll((mo >> (h_side * 32 + hs * K)) & ((1ull << K) - 1ull));
+                // (behind the owned sites' n0 entries; a counter of its own: n0 is still being read by slower waves)
+                const bool hp = h_act && v != CELL_EMPTY && pos >= 0 && pos < nfr;
+                const unsigned long long mh = __ballot(hp);
+                if (hp) plist[n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u))] = make_uint2((uint32_t)pos | ((uint32_t)hk << 16), v);
+                if (lane == 0) misc[4 + (it & 1)] = __popcll(mh);
+            }
         }
+        TLSTAMP(0)
         // ------------------------------------------------------------ 1  deposits of the previous step -> W, S of the frame
         W accP[RS], accM[RS], accF[RS], accWi[RS], accSi[RS];
 #pragma unroll
@@ -277,15 +346,11 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
         // 16 slots of each of the wave's four buckets per round: the valid ones go into the wave's segments by class.  Near a
         // reflecting wall the image of a deposit is the same deposit at the mirrored site (pass 1; small boxes: image
         // segment).  One more round after the last group (`drain`) sweeps what is left -- the sweep exists once in the code.
-        const int ngroups = (nbk + GB - 1) / GB;
-        const int npass = (wall && mirror_ok) ? 2 : 1;
 #pragma unroll 1
         for (int j = 0; j <= ngroups && !gave_up; ++j) {
             const bool drain = j == ngroups;
-            const int bi = j * GB + sub * FU_WAVES + wave;
-            const bool ok = !drain && bi < nbk;
-            int b = b0 + (ok ? bi : 0);
-            if (b >= a.ntile) b -= a.ntile;
+            bool ok;
+            const int b = bucket_of(j, ok);
             uint32_t cnt = 0u;
             if (first) { cnt = min(dcnt_e[(unsigned)b], (uint32_t)a.dcap); if (!ok) cnt = 0u; }   // the lists the previous launch left in the plain arrays
             const unsigned long long *rb = rec_in + (size_t)b * la.rec;                             // else: the records of the previous iteration
@@ -299,8 +364,15 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
                     en = dep_e[(unsigned)b * (unsigned)a.dcap + min(k0 + slot, (uint32_t)a.dcap - 1u)];
                     valid = k0 + slot < cnt; more = k0 + NSLOT < cnt;
                 } else if (__ballot(active)) {
-                    en = wait_granule(rb + min(page * NSLOT + slot, la.drec - 1), active);
-                    if (gave_up) break;
+                    if (page == 0 && j < TL_NG) {              // arrived above
+                        unsigned long long x = xg[0];
+#pragma unroll
+                        for (int g = 1; g < TL_NG; ++g) if (j == g) x = xg[g];
+                        en = (uint32_t)x;
+                    } else {
+                        en = wait_granule(rb + min(page * NSLOT + slot, la.drec - 1), active);
+                        if (gave_up) break;
+                    }
                     valid = active && en != DEP_NULL;
                     // a bucket has another page iff the last slot of this one is taken
                     const unsigned long long mv = __ballot(valid);
@@ -335,43 +407,33 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
                 if (ds != 0) tl_lds_add(&fieldS[r * 64 + lane], ds);
             }
         } else if (lane == 0) misc[TL_ABORT] = 1;
-        TLSTAMP(0)
-        __syncthreads();                                       // B: field and cells of the frame complete
         TLSTAMP(1)
+        __syncthreads();                                       // B: field, cells, occupancy and particle list of the frame complete
+        TLSTAMP(7)
         if (misc[TL_ABORT]) return;                            // uniform: some wait ran out (here or in another workgroup)
-        // ------------------------------------------------------------ 2  occupancy, the frame's particles
-        for (int i = t; i < TS + 2; i += FU_THREADS) {
-            int n = 0;
-            for (int k = 0; k < K; ++k) n += cellL[i * K + k] != CELL_EMPTY;
-            occL[i] = (uint8_t)n;
-        }
-        for (int c0 = 0; c0 < ncell; c0 += FU_THREADS) {       // uniform trip count
-            const int c = c0 + t;
-            const int pos = K1 ? c - 1 : c / K - 1, k = K1 ? 0 : c - (pos + 1) * K;
-            const uint32_t cw = c < ncell ? cellL[c] : CELL_EMPTY;
-            const bool occ = cw != CELL_EMPTY && pos >= 0 && pos < nfr;
-            const unsigned long long mm = __ballot(occ);
-            const int cnt_u = __popcll(mm);
-            int base = 0;
-            if (lane == 0 && cnt_u) base = atomicAdd(pcount, cnt_u);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (occ) plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)pos | ((uint32_t)k << 16), cw);
-        }
-        __syncthreads();                                       // C
-        TLSTAMP(2)
-        // ------------------------------------------------------------ 2b proposals, a lane per particle
+        // ------------------------------------------------------------ 2  proposals, a lane per particle
         {
             const Model M = *a.model;                          // uniform address: scalar loads, only now
-            const int n_part = *pcount;
-            for (int j = t; j < n_part; j += FU_THREADS) {
-                const uint2 pc = plist[j];
-                uint32_t x[4];
-                philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
+            const int n_part = n0 + misc[4 + (it & 1)];
+            auto propose_one = [&](const uint2 pc, const uint32_t (&x)[4]) {
                 const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16);
                 const int s = frame_site(pos);
                 const bool anch = a.anchor ? a.anchor[s] != 0 : false;
                 propL[pos * K + k] = decide_proposal(M, anch, s, (pc.y & CELL_PLUS) ? 1 : -1, (pc.y & CELL_BOUND) != 0,
                                                      clip_field((double)fieldS[pos], (double)fieldW[pos]), beta, occL[pos + 1], occL[pos], occL[pos + 2], x);
+            };
+            if (t < n_part) {
+                if (t >= n0) {                                 // a halo particle that joined after the random numbers were drawn
+                    mine = plist[t];
+                    philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), mine.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, rx);
+                }
+                propose_one(mine, rx);
+            }
+            for (int j = FU_THREADS + t; j < n_part; j += FU_THREADS) {   // more than 256 particles on the frame
+                const uint2 pc = plist[j];
+                uint32_t x[4];
+                philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
+                propose_one(pc, x);
             }
         }
         __syncthreads();                                       // D
@@ -390,9 +452,10 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
         auto cap_at = [&](int j) -> int { const int c = K - (int)occL[j + 1]; return c < 1 ? 1 : (c > 32 ? 32 : c); };
         auto put_deposit = [&](int kd, uint32_t d) { if (last) dep_o[kd] = d; else tl_store_granule(rec_out + kd, tag_out, d); };
         uint32_t newc[NOLD];                                   // K = 1: the owned sites' cells after this step
+        int newn[NOLD];                                        // particles on the site after this step
 #pragma unroll
         for (int r = 0; r < NOLD; ++r) {
-            newc[r] = CELL_EMPTY;
+            newc[r] = CELL_EMPTY; newn[r] = 0;
             const int xi = r * FU_THREADS + t;
             if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
             const int s = frame_site(xi);
@@ -430,35 +493,38 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
                 if (cr_ != CELL_EMPTY && er == EV_LEFT && rank_at(xi, cr_ & CELL_ID) < cap) emit(cr_);
             }
             if (!K1) for (int k = n_out; k < K; ++k) outN[k] = CELL_EMPTY;
+            newn[r] = n_out;
         }
-        __syncthreads();                                       // E: nobody reads this step's cells and proposals any more
+        __syncthreads();                                       // E: nobody reads this step's cells, proposals, occupancy and list any more
         TLSTAMP(4)
-        // ------------------------------------------------------------ 5  hand over: new cells, this tile's record (or the plain arrays)
+        // ------------------------------------------------------------ 5  hand over: new cells, this tile's record (or the plain arrays),
+        //                                                                 next iteration's list and occupancy of the owned sites
         const int count = min(*dcount, a.dcap);
+        int *pnext = misc + 2 + ((it + 1) & 1);
 #pragma unroll
         for (int r = 0; r < NOLD; ++r) {
             const int xi = r * FU_THREADS + t;
-            if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
+            const bool mine_site = !(xi < 2 || xi >= 2 + own_n || xi >= TS);
             const int io = xi - 2;
-#ifdef APS_LOOP_DEBUG
-            if (la.dbg) { la.dbg[((size_t)it * 3 + 1) * L + frame_site(xi)] = (uint32_t)occL[xi + 1] | ((uint32_t)propL[xi * K] << 8) | ((uint32_t)occL[xi] << 16) | ((uint32_t)occL[xi + 2] << 24);
-                          la.dbg[((size_t)it * 3 + 2) * L + frame_site(xi)] = cellL[(xi + 1) * K]; }
-#endif
-            for (int k = 0; k < K; ++k) {
-                const uint32_t c = K1 ? newc[r] : cellN[(xi + 1) * K + k];
-#ifdef APS_LOOP_DEBUG
-                if (la.dbg && k == 0) la.dbg[((size_t)it * 3 + 0) * L + frame_site(xi)] = c;
-#endif
-                cellL[(xi + 1) * K + k] = c;
-                if (last) cell_o[(unsigned)frame_site(xi) * (unsigned)K + (unsigned)k] = c;
-                else {
-                    if (io < 3) tl_store_granule(rec_out + la.drec + io * K + k, tag_out, c);
-                    if (io >= own_n - 3) tl_store_granule(rec_out + la.drec + 3 * K + (io - (own_n - 3)) * K + k, tag_out, c);
+            for (int k = 0; k < K; ++k) {                      // (uniform trip count: the list's ballots)
+                uint32_t c = CELL_EMPTY;
+                if (mine_site) {
+                    c = K1 ? newc[r] : cellN[(xi + 1) * K + k];
+                    cellL[(xi + 1) * K + k] = c;
+                    if (last) cell_o[(unsigned)frame_site(xi) * (unsigned)K + (unsigned)k] = c;
+                    else {
+                        if (io < 3) tl_store_granule(rec_out + la.drec + io * K + k, tag_out, c);
+                        if (io >= own_n - 3) tl_store_granule(rec_out + la.drec + 3 * K + (io - (own_n - 3)) * K + k, tag_out, c);
+                    }
                 }
+                if (!last) append(mine_site && c != CELL_EMPTY, xi, k, c, pnext);
             }
-            if (last) {
-                WS f; f.x = fieldW[xi]; f.y = fieldS[xi];
-                reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
+            if (mine_site) {
+                occL[xi + 1] = (uint8_t)newn[r];
+                if (last) {
+                    WS f; f.x = fieldW[xi]; f.y = fieldS[xi];
+                    reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
+                }
             }
         }
         if (!last && t < NSLOT) {                              // the rest of the record's last page: empty slots (at least one)
@@ -467,14 +533,25 @@ __global__ __launch_bounds__(FU_THREADS, 3) void tile_loop(const LoopArgs la, co
         }
         for (int i = t; i < (TS * K + 3) / 4; i += FU_THREADS) reinterpret_cast<uint32_t *>(propL)[i] = 0u;
         if (t == 0) {
-            misc[(it + 1) & 1] = 0; misc[2 + ((it + 1) & 1)] = 0;        // the next iteration's counters
+            misc[(it + 1) & 1] = 0;                            // the next iteration's deposit counter (this one's is still being read)
+            misc[2 + (it & 1)] = 0; misc[4 + (it & 1)] = 0;    // this iteration's particle counters: used again in two iterations
             if (last) {
                 a.dcnt_out[(size_t)e * a.ntile + tile] = (uint32_t)count;
                 if (tile == 0 && e == 0) a.stepw[a.par ^ 1] = la.step0 + (unsigned long long)la.nsteps;
             }
         }
-        // (no barrier here: the next iteration touches none of these words before its barrier B)
+        if (!last) {                                           // ask for the next iteration's records now: in flight across the barrier and the random numbers
+            const unsigned long long *rn = la.xrec + ((size_t)(it & 1) * a.E * a.ntile + rec_e) * la.rec;
+#pragma unroll
+            for (int g = 0; g < TL_NG; ++g) {
+                bool ok;
+                const int b = bucket_of(g, ok);
+                xg[g] = ok ? tl_load_granule(rn + (size_t)b * la.rec + slot) : 0ull;
+            }
+            xh = h_act ? tl_load_granule(rn + (size_t)h_nb * la.rec + la.drec + (h_side ? 0 : 3 * K) + h_i) : 0ull;
+        }
         TLSTAMP(5)
+        __syncthreads();                                       // F: list and occupancy of the owned sites complete
     }
 #ifdef APS_LOOP_STAMPS
     if (t == 0 && tile < 4096 && e == 0) {

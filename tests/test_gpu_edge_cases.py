@@ -119,9 +119,11 @@ def test_communicator_argument_and_ordering_errors(capi):
             b.comm_selftest()                                                     # no communicator
         with pytest.raises(capi.ApsError, match="already"):
             a.comm_init(capi.comm_unique_id())
-        a.step(37)                                                                # step by step (a communicator disables nothing else)
+        a.step(37)                                                                # a communicator on a one-rank handle: hipGraph replay, not the resident loop
+        assert a.step_info() == (37, 0) and a.loop_info()[0] == 0
+        b.set_resident_loop(False)
         b.step(37)                                                                # hipGraph replay: 32 + 4 + 1
-        assert b.step_info() == (37, 0)
+        assert b.step_info() == (37, 0) and b.loop_info()[0] == 0
         for _ in range(37):
             c.propose()
             c.commit()

@@ -44,6 +44,7 @@ LOOP_CASES = [
     dict(tag="dense_diffusive", L=1280, K=1, sigma=0.05, frac=0.9, rate_diffusion=6.0),
     dict(tag="ragged_last_tile", L=60 * 7 + 5, K=1, sigma=0.03, frac=0.5),
     dict(tag="single_tile_torus", L=50, K=2, sigma=0.1, periodic=True, frac=0.5),
+    dict(tag="two_workgroups_per_cu_geometry", L=70000, K=1, sigma=0.002, frac=0.4),   # 512 tiles of 137 sites (ts_choose_geometry)
 ]
 
 
@@ -81,7 +82,7 @@ def test_resident_loop_equals_oracle(capi, case, fp32):
 
 
 def test_resident_loop_equals_one_launch_per_step_at_config2(capi):
-    """BASELINE config 2 at full size (N = 1e5, L = 2e5, K = 1, 4001-tap table): 633 tiles resident at once.  The loop
+    """BASELINE config 2 at full size (N = 1e5, L = 2e5, K = 1, 4001-tap table): 512 tiles resident at once.  The loop
     against the per-step path over 401 steps (state, {W, S}, occupancy on all sites) and against the oracle over 5."""
     L, N = 200000, 100000
     par = params(L=L, K=1, sigma=0.005, rate_diffusion=0.02, rate_active=5.0, beta=0.7)
