@@ -291,6 +291,18 @@ def main():
             raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={os.environ['WORLD_SIZE']} of the launcher")
+    # a rank that hangs (a collective that never completes on some fabric) must not sit there until the caller's own limit:
+    # after APS_BENCH_WATCHDOG_S seconds (default 900) the process says so and leaves with code 124; a launcher or
+    # spawn_ranks then ends the other ranks
+    import threading
+    limit = float(os.environ.get("APS_BENCH_WATCHDOG_S", "900"))
+
+    def _give_up():
+        print(f"bench.py: rank {os.environ.get('RANK', '0')}: no result after {limit:.0f} s -- giving up (exit 124)", file=sys.stderr, flush=True)
+        os._exit(124)
+    dog = threading.Timer(limit, _give_up)
+    dog.daemon = True
+    dog.start()
     if args.workload == "pde":
         return bench_pde(args)
     if args.workload == "gillespie":

@@ -38,6 +38,29 @@ def test_committed_bench_line_has_the_contract_fields():
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == line["unit"]
 
 
+def test_committed_resident_loop_bench_line():
+    """The default bench line since the resident loop exists (csrc/tile_loop.hpp): the timed steps run inside one launch; the
+    roofline object prices that launch (per-step algorithmic bytes x its steps over its duration, timed by events on the
+    dispatch), traffic is the recorded per-step counter figure scaled to the launch."""
+    for name, steps in (("r02_loop_bench_config2.json", 2001), ("r02_loop_bench_config2_driver_form.json", 20)):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            line = json.load(f)
+        for key in CONTRACT[:-1]:
+            assert key in line, key
+        assert line["steps"] == steps and line["n_gpus"] == 1 and line["dtype"] == "f64"
+        assert line["resident_loop"] == "used" and line["steps_in_resident_loop"] == (steps if steps & 1 else steps - 1)
+        assert line["steps_from_graphs"] + line["steps_launched_singly"] + line["steps_in_resident_loop"] == steps
+        assert abs(line["value"] - 100000 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+        roof = line["roofline"]
+        assert roof["kernel"] == "tile_loop" and roof["steps_per_launch"] == line["steps_in_resident_loop"]
+        assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * roof["achieved"]
+        assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-12
+        per_step = roof["per_kernel"]["tile_step"]["algorithmic_bytes_per_launch"]
+        assert abs(roof["algorithmic_bytes_per_launch"] - per_step * roof["steps_per_launch"]) < 1e-6 * roof["algorithmic_bytes_per_launch"]
+        # the launch cannot be shorter than the steps it takes inside the timed region allow
+        assert roof["avg_launch_us"] <= line["ms_per_step"] * 1e3 * steps
+
+
 def test_bench_refuses_to_run_without_a_gpu():
     import torch
     if torch.cuda.is_available():
