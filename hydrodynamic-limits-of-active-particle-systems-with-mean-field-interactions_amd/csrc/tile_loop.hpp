@@ -459,6 +459,45 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
             const int xi = r * FU_THREADS + t;
             if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
             const int s = frame_site(xi);
+            if constexpr (K1) {
+                // One cell per site: a hop is only ever proposed into a site that was empty at the start of the step
+                // (channels(): open_l / open_r), so its capacity is 1 and the only rival is the particle on the far side of the
+                // target -- the rule of DESIGN 3 (smaller id wins) on a window of five sites, read once.
+                const uint32_t cm2 = cellL[xi - 1], cm1 = cellL[xi], c0 = cellL[xi + 1], cp1 = cellL[xi + 2], cp2 = cellL[xi + 3];
+                const int pm2 = propL[xi - 2] & 7, pm1 = propL[xi - 1] & 7, p0 = propL[xi] & 7, pp1 = propL[xi + 1] & 7, pp2 = xi + 2 < TS ? propL[xi + 2] & 7 : 0;
+                const bool from_l2 = cm2 != CELL_EMPTY && (pm2 == EV_RIGHT || pm2 == EV_FWD);     // the particle two sites left wants xi - 1
+                const bool from_l1 = cm1 != CELL_EMPTY && (pm1 == EV_RIGHT || pm1 == EV_FWD);     // the left neighbour wants this site
+                const bool from_r1 = cp1 != CELL_EMPTY && pp1 == EV_LEFT;                          // the right neighbour wants this site
+                const bool from_r2 = cp2 != CELL_EMPTY && pp2 == EV_LEFT;                          // the particle two sites right wants xi + 1
+                uint32_t c = c0;
+                if (c != CELL_EMPTY) {
+                    const int sgn = (c & CELL_PLUS) ? 1 : -1;
+                    uint32_t d0 = 0, d1 = 0;
+                    int nd = 0;
+                    bool stays = true;
+                    if (p0 == EV_LEFT || p0 == EV_RIGHT || p0 == EV_FWD) {
+                        const bool left = p0 == EV_LEFT;
+                        // rivals for the target: the other neighbour of the target site, if it proposes into it with a smaller id
+                        const int rivals = left ? (int)(from_l2 && (cm2 & CELL_ID) < (c & CELL_ID)) + (int)(false)
+                                                : (int)(from_r2 && (cp2 & CELL_ID) < (c & CELL_ID));
+                        if (rivals < 1) {
+                            stays = false;
+                            d0 = deposit(s, -1, -sgn); d1 = deposit(frame_site(left ? xi - 1 : xi + 1), 1, sgn); nd = 2;
+                        }
+                    } else if (p0 == EV_BIND) c |= CELL_BOUND;
+                    else if (p0 == EV_UNBIND) c &= ~CELL_BOUND;
+                    else if (p0 == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
+                    if (stays) { newc[r] = c; newn[r] = 1; }
+                    if (nd) {
+                        const int kd = atomicAdd(dcount, nd);
+                        if (kd + nd <= a.dcap) { put_deposit(kd, d0); if (nd == 2) put_deposit(kd + 1, d1); }
+                    }
+                }
+                // granted arrivals (capacity of this site: max(1, 1 - occupancy) = 1; a rival is the other neighbour with a smaller id)
+                if (from_l1 && !(from_r1 && (cp1 & CELL_ID) < (cm1 & CELL_ID))) { newc[r] = cm1; newn[r] += 1; }
+                if (from_r1 && !(from_l1 && (cm1 & CELL_ID) < (cp1 & CELL_ID))) { newc[r] = cp1; newn[r] += 1; }
+                continue;
+            }
             uint32_t *outN = cellN + (xi + 1) * K;
             int n_out = 0;
             auto emit = [&](uint32_t c) { if (K1) newc[r] = c; else outN[n_out] = c; ++n_out; };

@@ -16,6 +16,7 @@ capi.LIB_PATH = lib
 import bench
 w = dict(bench.WORK)
 if os.environ.get("DBG_FP32"): w["fp32"] = True
+final = {}
 for loop in (True, False):
     h = bench.make_handle(capi, w, method="tiles")
     h.set_resident_loop(loop)
@@ -25,4 +26,6 @@ for loop in (True, False):
     for _ in range(5):
         t0 = time.perf_counter(); h.step(2001); ts.append((time.perf_counter() - t0) / 2001 * 1e6)
     print("R", R, "OWN", os.environ.get("APS_TS_OWN"), "loop" if loop else "per-step", h.loop_info()[:2], "us/step", [round(x, 2) for x in ts])
+    final[loop] = h.get_state() + h.get_lattice()
     h.close()
+print("loop == per-step (state and lattice arrays):", all(np.array_equal(x, y) for x, y in zip(final[True], final[False])))
