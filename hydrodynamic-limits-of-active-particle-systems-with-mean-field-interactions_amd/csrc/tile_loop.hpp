@@ -21,8 +21,8 @@
 // the same bits either way: the arithmetic and the random numbers are tile_step's.
 #pragma once
 
-constexpr int TL_SEG_MIN = 88;             // entries per deposit segment of a wave at least (three workgroups per CU at config 2's 37 KB table: <= 42 LDS granules of 1280 B);
-                                           // the host takes up to 256 when the residency the grid needs leaves room (fewer, larger sweeps)
+constexpr int TL_SEG_MIN = 88;             // the four pooled deposit lists hold 4 (seg + 4) entries each; 88 at least (three workgroups per CU at config 2's 37 KB
+                                           // table: <= 42 LDS granules of 1280 B), the host takes up to 256 when the residency the grid needs leaves room
 constexpr int TL_NG = 2;                   // bucket groups whose first page a wave asks for ahead of time (config 2 has two)
 constexpr int TL_ABORT = 31;               // misc word: this workgroup leaves (a wait ran out, here or elsewhere)
 
@@ -32,7 +32,7 @@ struct LoopArgs {
     int nsteps;                            // odd
     uint32_t tag0;                         // the records written in iteration s carry the tag tag0 + s + 1 (never 0, never reused)
     int rec, drec;                         // granules per record; deposit slots of a record (a multiple of 16 above dcap)
-    int seg;                               // entries per deposit segment of a wave (a multiple of 4)
+    int seg;                               // sizes the pooled deposit lists: 4 (seg + 4) entries per class (a multiple of 4)
     unsigned long long *xrec;              // [2][E][ntile][rec] {tag << 32 | word}
     unsigned *abort_dev, *abort_host;      // raised by a workgroup whose wait ran out
     unsigned long long timeout_ticks;      // of the 100 MHz clock
@@ -316,39 +316,35 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
         W accP[RS], accM[RS], accF[RS], accWi[RS], accSi[RS];
 #pragma unroll
         for (int r = 0; r < RS; ++r) accP[r] = accM[r] = accF[r] = accWi[r] = accSi[r] = 0;
-        int nP = 0, nM = 0, nF = 0, nI = 0;
-        const uint4 *segP4 = reinterpret_cast<const uint4 *>(segP), *segM4 = reinterpret_cast<const uint4 *>(segM),
-                    *segF4 = reinterpret_cast<const uint4 *>(segF), *segI4 = reinterpret_cast<const uint4 *>(segI);
-        auto flush = [&]() {
-            if (lane < 8) {
-                const uint32_t pad = DEP_NULL | ((uint32_t)null_site + TS_BIAS);
-                segP[nP + lane] = pad; segM[nM + lane] = pad; segF[nF + lane] = pad; segI[nI + lane] = DEP_NULL | ((uint32_t)x0c + TS_BIAS);
+        // The four waves POOL the deposits of their buckets into one list per class (P, M, F; I: image terms of a small box) --
+        // one packed LDS atomic per wave and round hands out the slots -- and after a barrier take whole groups of four from the
+        // lists in turn: every wave sweeps the same number of groups whatever its buckets held (a wave's own ~7 buckets vary
+        // by +-16 %), and a list is padded once, not once per wave.  An entry that finds its list full is swept at once by
+        // the wave that holds it.
+        uint32_t *shl = seg_all;                               // [4][CAP]
+        const int CAP = (FU_WAVES * 4 * (SEG + 4) / 4) & ~3;
+        unsigned long long *shcnt = reinterpret_cast<unsigned long long *>(misc + 8 + 2 * (it & 1));   // packed list lengths: 16 bits each
+        auto sweep_now = [&](unsigned long long m, const uint32_t word, const int cls) {   // overflow: one by one (never in practice)
+            while (m) {
+                const int src_lane = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)word, src_lane);
+                if (BC == 0) {
+                    if (cls == 0) ts_one_abs<RS, 0, F32>(e1, x8, tb, accP);
+                    else if (cls == 1) ts_one_abs<RS, 0, F32>(e1, x8, tb, accM);
+                    else if (cls == 2) ts_one_abs<RS, 1, F32>(e1, x8, tb, accF);
+                    else ts_image_group<TAB_LDS, RS, F32>(make_uint4(e1, DEP_NULL | ((uint32_t)x0c + TS_BIAS), DEP_NULL | ((uint32_t)x0c + TS_BIAS), DEP_NULL | ((uint32_t)x0c + TS_BIAS)),
+                                                          x8, tb, table_g, tlen8, L8, accWi, accSi);
+                } else {
+                    const uint4 q = make_uint4(e1, DEP_NULL | ((uint32_t)null_site + TS_BIAS), DEP_NULL | ((uint32_t)null_site + TS_BIAS), DEP_NULL | ((uint32_t)null_site + TS_BIAS));
+                    if (cls == 0) ts_group<1, TAB_LDS, RS, 0, F32>(q, x8, tb, table_g, tlen8, L8, accP);
+                    else if (cls == 1) ts_group<1, TAB_LDS, RS, 0, F32>(q, x8, tb, table_g, tlen8, L8, accM);
+                    else ts_group<1, TAB_LDS, RS, 1, F32>(q, x8, tb, table_g, tlen8, L8, accF);
+                }
             }
-#define TL_SWEEP(SEG4, N, MODE, ACC) { \
-            uint4 q = SEG4[0]; \
-            _Pragma("unroll 1") for (int i = 0; i < ((N) + 3) >> 2; ++i) { \
-                const uint4 qn = SEG4[i + 1]; \
-                if (BC == 1) ts_group<1, TAB_LDS, RS, MODE, F32>(q, x8, tb, table_g, tlen8, L8, ACC); \
-                else ts_group<0, TAB_LDS, RS, MODE, F32>(q, x8, tb, table_g, tlen8, L8, ACC); \
-                q = qn; } }
-            TL_SWEEP(segP4, nP, 0, accP)
-            TL_SWEEP(segM4, nM, 0, accM)
-            TL_SWEEP(segF4, nF, 1, accF)
-#undef TL_SWEEP
-#pragma unroll 1
-            for (int i = 0; i < (nI + 3) >> 2; ++i) ts_image_group<TAB_LDS, RS, F32>(segI4[i], x8, tb, table_g, tlen8, L8, accWi, accSi);
-            nP = nM = nF = nI = 0;
         };
-#define TL_PUT(SEGX, NX, COND, WORD) { const unsigned long long m_ = __ballot(COND); \
-            if (COND) SEGX[NX + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u))] = (WORD); \
-            NX += __popcll(m_); }
-#define TL_FULL() (nP + 64 > SEG - 4 || nM + 64 > SEG - 4 || nF + 64 > SEG - 4 || nI + 64 > SEG - 4)
-        // 16 slots of each of the wave's four buckets per round: the valid ones go into the wave's segments by class.  Near a
-        // reflecting wall the image of a deposit is the same deposit at the mirrored site (pass 1; small boxes: image
-        // segment).  One more round after the last group (`drain`) sweeps what is left -- the sweep exists once in the code.
 #pragma unroll 1
-        for (int j = 0; j <= ngroups && !gave_up; ++j) {
-            const bool drain = j == ngroups;
+        for (int j = 0; j < ngroups && !gave_up; ++j) {
             bool ok;
             const int b = bucket_of(j, ok);
             uint32_t cnt = 0u;
@@ -378,39 +374,93 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
                     const unsigned long long mv = __ballot(valid);
                     more = active && ((mv >> (sub * 16 + 15)) & 1ull) && (page + 1) * NSLOT < la.drec;
                 }
+                // by class; near a reflecting wall the image of a deposit is the same deposit at the mirrored site (small boxes: image list)
                 const uint32_t en_ = en + TS_BIAS;
                 const int dp = (int)(en & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2;
                 const bool img_l = valid && wall && (x0c + dp + 1 <= Rt), img_r = valid && wall && (2 * L - 1 - x1c - dp <= Rt);
                 const bool cP = cw != 0 && cw == cs, cM = cw != 0 && cw != cs, cF = cw == 0;
                 const bool im = img_l || img_r;
-                const bool pl = valid && (mirror_ok || !im);
+                const bool pl = valid && (mirror_ok || !im), mi = im && mirror_ok, ii = valid && im && !mirror_ok;
                 const uint32_t mir = (en_ & ~POS_MASK) | (uint32_t)((int)TS_BIAS + (img_l ? -1 - dp : 2 * L - 1 - dp));
-#pragma unroll 1
-                for (int pass = 0; pass < npass; ++pass) {
-                    if (drain || TL_FULL()) flush();
-                    const bool c_ = pass ? im : pl;
-                    const uint32_t w_ = pass ? mir : en_;
-                    TL_PUT(segP, nP, (c_ && cP), w_) TL_PUT(segM, nM, (c_ && cM), w_) TL_PUT(segF, nF, (c_ && cF), w_)
-                    if (wall && !mirror_ok) TL_PUT(segI, nI, (valid && im), en_)
+                const unsigned long long kP = __ballot(pl && cP), kM = __ballot(pl && cM), kF = __ballot(pl && cF);
+                const unsigned long long gP = __ballot(mi && cP), gM = __ballot(mi && cM), gF = __ballot(mi && cF), kI = __ballot(ii);
+                const unsigned long long add = (unsigned long long)(__popcll(kP) + __popcll(gP)) | ((unsigned long long)(__popcll(kM) + __popcll(gM)) << 16) |
+                                               ((unsigned long long)(__popcll(kF) + __popcll(gF)) << 32) | ((unsigned long long)__popcll(kI) << 48);
+                if (add) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(shcnt, add);
+                    const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+#define TL_POOL(MASK, COND, WORD, CLS, BASE) { \
+                    const int i_ = (int)(BASE) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((MASK) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(MASK), 0u)); \
+                    if ((COND) && i_ < CAP) shl[(CLS) * CAP + i_] = (WORD); \
+                    const unsigned long long o_ = __ballot((COND) && i_ >= CAP); \
+                    if (o_) sweep_now(o_, (WORD), (CLS)); }
+                    TL_POOL(kP, (pl && cP), en_, 0, blo & 0xFFFFu) TL_POOL(gP, (mi && cP), mir, 0, (blo & 0xFFFFu) + __popcll(kP))
+                    TL_POOL(kM, (pl && cM), en_, 1, blo >> 16) TL_POOL(gM, (mi && cM), mir, 1, (blo >> 16) + __popcll(kM))
+                    TL_POOL(kF, (pl && cF), en_, 2, bhi & 0xFFFFu) TL_POOL(gF, (mi && cF), mir, 2, (bhi & 0xFFFFu) + __popcll(kF))
+                    TL_POOL(kI, ii, en_, 3, bhi >> 16)
+#undef TL_POOL
                 }
                 active = more;
                 if (!__ballot(active)) break;
             }
         }
-#undef TL_FULL
-#undef TL_PUT
-        if (!gave_up) {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) {                     // W = P + M, S = P - M + F (+ the image deposits), exact on the weight grid
-                const W dw = (accP[r] + accM[r]) + accWi[r], ds = ((accP[r] - accM[r]) + accF[r]) + accSi[r];
-                if (dw != 0) tl_lds_add(&fieldW[r * 64 + lane], dw);
-                if (ds != 0) tl_lds_add(&fieldS[r * 64 + lane], ds);
+        if (gave_up && lane == 0) misc[TL_ABORT] = 1;
+        TLSTAMP(1)
+        __syncthreads();                                       // S: the lists are complete
+        if (misc[TL_ABORT]) return;                            // uniform: some wait ran out (here or in another workgroup)
+        {
+            const unsigned long long tot = *shcnt;
+            const int nP = min((int)(tot & 0xFFFFu), CAP), nM = min((int)((tot >> 16) & 0xFFFFu), CAP), nF = min((int)((tot >> 32) & 0xFFFFu), CAP),
+                      nI = min((int)(tot >> 48), CAP);
+            const uint32_t nullw = DEP_NULL | ((uint32_t)null_site + TS_BIAS);
+            int rot = wave;                                    // whole groups of four are dealt round-robin across the lists
+#define TL_SHARED(CLS, N, CALL4) { \
+            const int ng_ = ((N) + 3) >> 2; \
+            const uint4 *l4 = reinterpret_cast<const uint4 *>(shl + (CLS) * CAP); \
+            int g = rot & 3; \
+            uint4 q = l4[min(g, CAP / 4 - 1)]; \
+            _Pragma("unroll 1") for (; g < ng_; g += FU_WAVES) { \
+                const uint4 qn = l4[min(g + FU_WAVES, CAP / 4 - 1)]; \
+                if (4 * g + 3 >= (N)) {                        /* the list's last group: null deposits behind its end */ \
+                    if (4 * g + 1 >= (N)) q.y = nullw; \
+                    if (4 * g + 2 >= (N)) q.z = nullw; \
+                    q.w = nullw; } \
+                CALL4; \
+                q = qn; } \
+            rot = (rot - ng_) & 3; }
+            if (BC == 1) {
+                TL_SHARED(0, nP, (ts_group<1, TAB_LDS, RS, 0, F32>(q, x8, tb, table_g, tlen8, L8, accP)))
+                TL_SHARED(1, nM, (ts_group<1, TAB_LDS, RS, 0, F32>(q, x8, tb, table_g, tlen8, L8, accM)))
+                TL_SHARED(2, nF, (ts_group<1, TAB_LDS, RS, 1, F32>(q, x8, tb, table_g, tlen8, L8, accF)))
+            } else {
+                TL_SHARED(0, nP, (ts_group<0, TAB_LDS, RS, 0, F32>(q, x8, tb, table_g, tlen8, L8, accP)))
+                TL_SHARED(1, nM, (ts_group<0, TAB_LDS, RS, 0, F32>(q, x8, tb, table_g, tlen8, L8, accM)))
+                TL_SHARED(2, nF, (ts_group<0, TAB_LDS, RS, 1, F32>(q, x8, tb, table_g, tlen8, L8, accF)))
             }
-        } else if (lane == 0) misc[TL_ABORT] = 1;
+#undef TL_SHARED
+            if (nI) {
+                const uint32_t nulli = DEP_NULL | ((uint32_t)x0c + TS_BIAS);
+                const uint4 *l4 = reinterpret_cast<const uint4 *>(shl + 3 * CAP);
+#pragma unroll 1
+                for (int g = rot & 3; g < (nI + 3) >> 2; g += FU_WAVES) {
+                    uint4 q = l4[g];
+                    if (4 * g + 1 >= nI) q.y = nulli;
+                    if (4 * g + 2 >= nI) q.z = nulli;
+                    if (4 * g + 3 >= nI) q.w = nulli;
+                    ts_image_group<TAB_LDS, RS, F32>(q, x8, tb, table_g, tlen8, L8, accWi, accSi);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {                         // W = P + M, S = P - M + F (+ the image deposits), exact on the weight grid
+            const W dw = (accP[r] + accM[r]) + accWi[r], ds = ((accP[r] - accM[r]) + accF[r]) + accSi[r];
+            if (dw != 0) tl_lds_add(&fieldW[r * 64 + lane], dw);
+            if (ds != 0) tl_lds_add(&fieldS[r * 64 + lane], ds);
+        }
         TLSTAMP(1)
         __syncthreads();                                       // B: field, cells, occupancy and particle list of the frame complete
         TLSTAMP(7)
-        if (misc[TL_ABORT]) return;                            // uniform: some wait ran out (here or in another workgroup)
         // ------------------------------------------------------------ 2  proposals, a lane per particle
         {
             const Model M = *a.model;                          // uniform address: scalar loads, only now
@@ -574,6 +624,7 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
         if (t == 0) {
             misc[(it + 1) & 1] = 0;                            // the next iteration's deposit counter (this one's is still being read)
             misc[2 + (it & 1)] = 0; misc[4 + (it & 1)] = 0;    // this iteration's particle counters: used again in two iterations
+            misc[8 + 2 * (it & 1)] = 0; misc[9 + 2 * (it & 1)] = 0;   // and its list lengths
             if (last) {
                 a.dcnt_out[(size_t)e * a.ntile + tile] = (uint32_t)count;
                 if (tile == 0 && e == 0) a.stepw[a.par ^ 1] = la.step0 + (unsigned long long)la.nsteps;

@@ -44,6 +44,9 @@ LOOP_CASES = [
     dict(tag="dense_diffusive", L=1280, K=1, sigma=0.05, frac=0.9, rate_diffusion=6.0),
     dict(tag="ragged_last_tile", L=60 * 7 + 5, K=1, sigma=0.03, frac=0.5),
     dict(tag="single_tile_torus", L=50, K=2, sigma=0.1, periodic=True, frac=0.5),
+    # more deposits of one class in reach than a pooled list holds (1040): the entries that find it full are swept one by one
+    dict(tag="overflowing_lists_torus", L=1200, K=3, sigma=0.4, periodic=True, frac=0.95, rate_diffusion=6.0),
+    dict(tag="overflowing_lists_small_box_images", L=1200, K=3, sigma=0.3, frac=0.95, rate_diffusion=6.0),
     dict(tag="two_workgroups_per_cu_geometry", L=70000, K=1, sigma=0.002, frac=0.4),   # 512 tiles of 137 sites (ts_choose_geometry)
 ]
 

@@ -30,11 +30,11 @@ st = buf.reshape(-1, 8)
 idx = np.flatnonzero(st[:, 6] > 0)
 st = st[idx].astype(float) / steps
 print("workgroups", len(st), "; cycles per iteration (s_memtime, 100 MHz? see total vs wall), wave 0 of each workgroup")
-for k, name in ((2, "barrier F + random numbers"), (0, "wait for the records"), (1, "intake + sweep"), (7, "barrier B"), (3, "proposals (D)"), (4, "exclusion (E)"),
+for k, name in ((2, "barrier F + random numbers"), (0, "wait for the records"), (1, "intake, barrier S, sweep"), (7, "barrier B"), (3, "proposals (D)"), (4, "exclusion (E)"),
                 (5, "hand over + ask ahead"), (6, "total")):
     print(f"  {name:24s} mean {st[:, k].mean():9.1f}   median {np.median(st[:, k]):9.1f}   min {st[:, k].min():9.1f}   max {st[:, k].max():9.1f}")
 worst = np.argsort(-st[:, 1])[:8]
-print("  longest intake+sweep: tiles", idx[worst], st[worst, 1].round(0), " their waits", st[worst, 0].round(0))
+print("  longest intake .. sweep: tiles", idx[worst], st[worst, 1].round(0), " their waits", st[worst, 0].round(0))
 best = np.argsort(st[:, 0])[:8]
 print("  shortest waits: tiles", idx[best], st[best, 0].round(0), "their intake+sweep", st[best, 1].round(0))
 h.close()
