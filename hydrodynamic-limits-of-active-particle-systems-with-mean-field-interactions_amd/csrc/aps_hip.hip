@@ -2366,6 +2366,12 @@ int aps_create(const aps_params *p, aps_handle **out) {
         const bool tiles_ok = p->n_particles < (int64_t)CELL_ID && dep_bytes <= 16e9 && (p->world == 1 || M.field_mode);
         if (p->method == APS_METHOD_TILES && !tiles_ok) { delete h; return bad("method tiles needs fewer than 2^30 - 1 particles and, sharded, a local field (sigma_grid > 0)"); }
         h->method = p->method == APS_METHOD_AUTO ? ((tiles_ok && p->world == 1) ? APS_METHOD_TILES : (dep_bytes <= 16e9 ? APS_METHOD_LATTICE : APS_METHOD_PAIRS)) : p->method;
+        // far beyond the caches (state of the binary64 field above 512 MB: N >~ 6e6 particles at half filling) the three streaming
+        // kernels of the lattice formulation move their bytes faster than one tile kernel with its per-tile prologue
+        // (measured at N = 1.6e7, L = 3.2e7: 0.68 ms against 0.85 ms per step; with the 32-bit field the tile kernel wins: 0.63 ms)
+        if (p->method == APS_METHOD_AUTO && h->method == APS_METHOD_TILES && !p->fp32 && dep_bytes <= 16e9 &&
+            (32.0 + 8.0 * p->K) * (double)p->L * (double)h->E > 512e6)
+            h->method = APS_METHOD_LATTICE;
         if (const char *env = std::getenv("APS_METHOD")) {    // test / tuning knob for method = auto
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "pairs")) h->method = APS_METHOD_PAIRS;
             if (p->method == APS_METHOD_AUTO && !std::strcmp(env, "lattice")) h->method = APS_METHOD_LATTICE;
