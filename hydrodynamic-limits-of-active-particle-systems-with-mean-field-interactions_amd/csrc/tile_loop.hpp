@@ -81,14 +81,14 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
     constexpr bool TAB_LDS = true;
     const TileArgs &a = la.a;
     const W *__restrict__ table_g = reinterpret_cast<const W *>(table_v);
-    constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS, NCR = (TS + 2 + FU_THREADS - 1) / FU_THREADS;
+    constexpr int TS = 64 * RS, NOLD = (TS + FU_THREADS - 1) / FU_THREADS;
     constexpr int NSLOT = 16, GB = FU_WAVES * 4;
     const int SEG = la.seg;
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
     const TlLds lay = tl_lds_layout(a.tlen, RS, OWN, K, WB, la.seg);
     char *lds_c = reinterpret_cast<char *>(lds);
-    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
+    uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);          // the pooled deposit lists: [4 classes][4 (seg + 4) entries]
     uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
     uint32_t *cellN = reinterpret_cast<uint32_t *>(lds_c + lay.cells2);      // K > 1: the cells after this step
     uint8_t *propL = reinterpret_cast<uint8_t *>(lds_c + lay.props);         // [TS K]
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
     W *fieldW = reinterpret_cast<W *>(lds_c + lay.fw), *fieldS = reinterpret_cast<W *>(lds_c + lay.fs);   // [TS] each: the frame's field, kept across the steps
     W *tab = reinterpret_cast<W *>(lds_c + lay.tab);
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), e = blockIdx.y;
-    uint32_t *segP = seg_all + wave * 4 * (SEG + 4), *segM = segP + SEG + 4, *segF = segM + SEG + 4, *segI = segF + SEG + 4;
     const int tile = (int)blockIdx.x;
     const int own0 = tile * OWN, own_n = min(OWN, L - own0), nfr = own_n + 4;
     const int x0 = own0 - 2;
