@@ -1381,9 +1381,12 @@ struct aps_handle {
     bool fu_table_in_lds = true;
     bool field_dirty = true;
     hipStream_t cap_stream = nullptr;
-    hipGraphExec_t gexec[2][6] = {};   // [start parity][k]: runs of GRAPH_SIZES[k] steps
-    hipGraphExec_t gexact[2][65] = {}; // [start parity][n]: a run of exactly n <= 64 steps, captured the first time aps_step(n) is called
-    bool graphs_built = false;
+    // captured graphs bake the buffer pointers in: one set per `flip` (which physical buffer set holds the even steps; the
+    // resident loop swaps the sets after a call of an even number of steps)
+    hipGraphExec_t gexec_f[2][2][6] = {};   // [flip][start parity][k]: runs of GRAPH_SIZES[k] steps
+    hipGraphExec_t gexact_f[2][2][65] = {}; // [flip][start parity][n]: a run of exactly n <= 64 steps, captured the first time aps_step(n) is called
+    bool graphs_built_f[2] = {false, false};
+    int flip = 0;
     int64_t last_graph_steps = 0, last_single_steps = 0;      // how the last aps_step call was executed
     // tiles formulation (site-centric state, one kernel per step): everything double buffered by step parity
     double2 *d_wsb[2] = {nullptr, nullptr};
@@ -1990,7 +1993,7 @@ int loop_prepare(aps_handle *h) {
     return APS_OK;
 }
 
-// n (odd) steps from the current state in one launch; the caller synchronises and looks at h_abort
+// n steps from the current state in one launch; the caller synchronises and looks at h_abort
 int launch_tile_loop(aps_handle *h, int64_t n) {
     LoopArgs la{};
     la.a = tile_args(h, false);
@@ -2653,22 +2656,22 @@ int capture_run(aps_handle *h, int par, int nsteps, hipGraphExec_t *out) {
 }
 
 int build_graphs(aps_handle *h) {
-    if (h->graphs_built) return APS_OK;
+    if (h->graphs_built_f[h->flip]) return APS_OK;
     for (int par = 0; par < 2; ++par)
         for (int g = 0; g < NGRAPH; ++g) {
-            int rc = capture_run(h, par, GRAPH_SIZES[g], &h->gexec[par][g]);
+            int rc = capture_run(h, par, GRAPH_SIZES[g], &h->gexec_f[h->flip][par][g]);
             if (rc) return rc;
         }
-    h->graphs_built = true;
+    h->graphs_built_f[h->flip] = true;
     return APS_OK;
 }
 
 void drop_graphs(aps_handle *h) {
     for (int par = 0; par < 2; ++par)
-        for (int g = 0; g < NGRAPH; ++g) if (h->gexec[par][g]) { (void)hipGraphExecDestroy(h->gexec[par][g]); h->gexec[par][g] = nullptr; }
+        for (int f = 0; f < 2; ++f) for (int g = 0; g < NGRAPH; ++g) if (h->gexec_f[f][par][g]) { (void)hipGraphExecDestroy(h->gexec_f[f][par][g]); h->gexec_f[f][par][g] = nullptr; }
     for (int par = 0; par < 2; ++par)
-        for (int n = 0; n <= 64; ++n) if (h->gexact[par][n]) { (void)hipGraphExecDestroy(h->gexact[par][n]); h->gexact[par][n] = nullptr; }
-    h->graphs_built = false;
+        for (int f = 0; f < 2; ++f) for (int n = 0; n <= 64; ++n) if (h->gexact_f[f][par][n]) { (void)hipGraphExecDestroy(h->gexact_f[f][par][n]); h->gexact_f[f][par][n] = nullptr; }
+    h->graphs_built_f[0] = h->graphs_built_f[1] = false;
 }
 
 int one_step(aps_handle *h) {
@@ -2755,10 +2758,10 @@ int aps_step(aps_handle *h, int64_t nsteps) {
         if (!(env && env[0] == '0')) {
             if ((rc = loop_prepare(h))) return rc;
             if (h->loop_state == 1) {
-                // the loop takes an odd number of steps (its final state lands in the other parity's buffers, its inputs stay
-                // intact): an even call takes one ordinary step first
-                if (!(nsteps & 1)) { if ((rc = one_step(h))) return rc; ++s; ++h->last_single_steps; }
-                const int64_t n = std::min<int64_t>(nsteps - s, (int64_t)1 << 30 | 1);
+                // the loop writes its final state into the buffer set of the OTHER parity whatever the step count, so its inputs
+                // stay intact for the fallback; after an even number of steps that set holds the state of the SAME parity:
+                // the two sets trade places (captured graphs are kept per `flip`)
+                const int64_t n = std::min<int64_t>(nsteps - s, (int64_t)1 << 30);
                 if ((rc = launch_tile_loop(h, n))) return rc;
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
 #ifdef APS_LOOP_DEBUG
@@ -2775,6 +2778,12 @@ int aps_step(aps_handle *h, int64_t nsteps) {
                 } else {
                     h->step += n; s += n; h->last_loop_steps = n;
                     h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true;
+                    if (!(n & 1)) {
+                        std::swap(h->d_cell[0], h->d_cell[1]); std::swap(h->d_wsb[0], h->d_wsb[1]); std::swap(h->d_wsi[0], h->d_wsi[1]);
+                        std::swap(h->d_tdcnt[0], h->d_tdcnt[1]); std::swap(h->d_tdep[0], h->d_tdep[1]); std::swap(h->d_gpart[0], h->d_gpart[1]);
+                        h->d_ws = h->d_wsb[h->step & 1];
+                        h->flip ^= 1;
+                    }
                 }
             }
         }
@@ -2784,7 +2793,7 @@ int aps_step(aps_handle *h, int64_t nsteps) {
         if (s == 0 && nsteps <= 64 && nsteps != 32 && nsteps != 16 && nsteps != 8 && nsteps != 4 && nsteps != 2 && nsteps != 1) {
             // a short call that is not one of the stock sizes: one graph of exactly that many steps (captured on first use),
             // one launch instead of several
-            hipGraphExec_t &ge = h->gexact[h->step & 1][nsteps];
+            hipGraphExec_t &ge = h->gexact_f[h->flip][h->step & 1][nsteps];
             if (!ge && (rc = capture_run(h, (int)(h->step & 1), (int)nsteps, &ge))) return rc;
             HIP_TRY(h, hipGraphLaunch(ge, h->stream));
             h->step += nsteps; h->last_graph_steps += nsteps; s = nsteps;
@@ -2792,7 +2801,7 @@ int aps_step(aps_handle *h, int64_t nsteps) {
         }
         for (int g = 0; g < NGRAPH; ++g)
             for (; nsteps - s >= GRAPH_SIZES[g]; s += GRAPH_SIZES[g]) {
-                HIP_TRY(h, hipGraphLaunch(h->gexec[h->step & 1][g], h->stream));
+                HIP_TRY(h, hipGraphLaunch(h->gexec_f[h->flip][h->step & 1][g], h->stream));
                 h->step += GRAPH_SIZES[g];
                 h->last_graph_steps += GRAPH_SIZES[g];
                 if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true; }
@@ -3244,7 +3253,7 @@ int aps_exchange_buffer(aps_handle *h, void **dev_ptr, int64_t *total_bytes, int
 
 int aps_bind_exchange_buffer(aps_handle *h, void *dev_ptr, int64_t nbytes) {
     if (!h) return APS_ERR_ARG;
-    if (h->graphs_built) { (void)hipStreamSynchronize(h->stream); drop_graphs(h); }   // captured kernels hold the old pointer
+    if (h->graphs_built_f[0] || h->graphs_built_f[1]) { (void)hipStreamSynchronize(h->stream); drop_graphs(h); }   // captured kernels hold the old pointer
     if (!dev_ptr) { h->d_prop = h->d_prop_own; return APS_OK; }
     if (nbytes < (int64_t)h->E * h->SH * h->world) return fail(h, APS_ERR_ARG, "aps_bind_exchange_buffer: buffer too small");
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -17,8 +17,8 @@
 //
 // Safety: every wait is bounded (s_memrealtime); a workgroup that gives up raises a flag that every other wait watches,
 // all workgroups leave, and the host repeats the call with one launch per step -- the loop writes the final state only
-// into the buffers of the other parity (the step count of a launch is odd), so the inputs are still intact.  Results are
-// the same bits either way: the arithmetic and the random numbers are tile_step's.
+// into the buffer set of the other parity, so the inputs are still intact (after an even number of steps the host lets the
+// two sets trade places).  Results are the same bits either way: the arithmetic and the random numbers are tile_step's.
 #pragma once
 
 constexpr int TL_SEG_MIN = 88;             // the four pooled deposit lists hold 4 (seg + 4) entries each; 88 at least (three workgroups per CU at config 2's 37 KB
@@ -29,7 +29,7 @@ constexpr int TL_ABORT = 31;               // misc word: this workgroup leaves (
 struct LoopArgs {
     TileArgs a;                            // buffers of the first step's parity: *_in = [par] (read once), *_out = [par ^ 1] (final state)
     unsigned long long step0;              // index of the first step
-    int nsteps;                            // odd
+    int nsteps;                            // any; the final state goes to the *_out buffers (the host swaps the two sets after an even count)
     uint32_t tag0;                         // the records written in iteration s carry the tag tag0 + s + 1 (never 0, never reused)
     int rec, drec;                         // granules per record; deposit slots of a record (a multiple of 16 above dcap)
     int seg;                               // sizes the pooled deposit lists: 4 (seg + 4) entries per class (a multiple of 4)
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
             misc[8 + 2 * (it & 1)] = 0; misc[9 + 2 * (it & 1)] = 0;   // and its list lengths
             if (last) {
                 a.dcnt_out[(size_t)e * a.ntile + tile] = (uint32_t)count;
-                if (tile == 0 && e == 0) a.stepw[a.par ^ 1] = la.step0 + (unsigned long long)la.nsteps;
+                if (tile == 0 && e == 0) a.stepw[(a.par + la.nsteps) & 1] = la.step0 + (unsigned long long)la.nsteps;   // (nobody reads the step words in here)
             }
         }
         if (!last) {                                           // ask for the next iteration's records now: in flight across the barrier and the random numbers
