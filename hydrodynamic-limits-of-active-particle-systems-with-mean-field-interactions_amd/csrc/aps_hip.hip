@@ -2751,7 +2751,11 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     int64_t s = 0;
     static const bool no_graph = std::getenv("APS_NO_GRAPH") != nullptr;
     h->last_graph_steps = h->last_single_steps = h->last_loop_steps = 0;
-    int64_t loop_min = 3;                                        // below that a call is not worth the loop's set-up
+    // Below that a call is not worth the loop's set-up: its launch costs ~22 us more than a graph replay (table and state
+    // staged once, the synchronisation that reads the give-up word) and gains ~2 us per step on a full device (config 2:
+    // break-even near 10 steps); a grid of at most one workgroup per CU gains more per step (reference-shaped runs with 7
+    // steps between observations: 43 ms with the loop against 47 ms)
+    int64_t loop_min = (int64_t)h->ts_ntile * h->E > h->num_cu ? 10 : 3;
     if (const char *env = std::getenv("APS_LOOP_MIN")) loop_min = std::max(1, std::atoi(env));
     if (is_tiles(h) && h->world == 1 && !h->comm && h->loop_wanted && nsteps >= loop_min && h->loop_state != 0 && h->loop_state != -1) {
         const char *env = std::getenv("APS_TILE_LOOP");

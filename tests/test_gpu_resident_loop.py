@@ -65,6 +65,7 @@ def test_resident_loop_equals_oracle(capi, case, fp32):
     orc = so.SyncOracle(par, dt=dt, seed=seed, **kw)
     orc.set_state(pos, spin)
     h = make_handle(capi, par, N, dt=dt, seed=seed, method="tiles", fp32=fp32)
+    os.environ["APS_LOOP_MIN"] = "3"                     # (a grid of more than one workgroup per CU starts at 10 steps by default)
     try:
         h.set_state(pos, spin)
         total = 0
@@ -81,6 +82,7 @@ def test_resident_loop_equals_oracle(capi, case, fp32):
         assert k == total
         assert not np.array_equal(h.get_state()[0], pos)
     finally:
+        del os.environ["APS_LOOP_MIN"]
         h.close()
 
 
@@ -101,7 +103,11 @@ def test_resident_loop_equals_one_launch_per_step_at_config2(capi):
         b.set_resident_loop(False)
         a.set_state(pos, spin)
         b.set_state(pos, spin)
-        a.step(5)
+        os.environ["APS_LOOP_MIN"] = "3"                 # a full device takes the loop from 10 steps on by default
+        try:
+            a.step(5)
+        finally:
+            del os.environ["APS_LOOP_MIN"]
         b.step(5)
         orc.run(5)
         assert a.loop_info()[:2] == (5, 1), a.loop_info()
@@ -109,7 +115,10 @@ def test_resident_loop_equals_one_launch_per_step_at_config2(capi):
         same_state(a, orc)
         same_state(b, orc)
         check_lattice(a, orc)
-        for n in (200, 196):
+        a.step(6)                                        # default: a full device takes the loop from 10 steps on
+        b.step(6)
+        assert a.loop_info()[0] == 0 and a.step_info()[0] == 6
+        for n in (200, 190):
             a.step(n)
             b.step(n)
             assert a.loop_info()[0] == n
