@@ -593,6 +593,10 @@ def main():
                     "whole_step": {"algorithmic_bytes": step_bytes, "us_per_step": us_step,
                                    "achieved_GBps": step_bytes / (us_step * 1e-6) / 1e9,
                                    "frac": step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                    "note": ("algorithmic bytes = what a step must read and write when the state streams through HBM ((32 + 8K) B per site + the deposits); "
+                             "inside the resident loop the state stays in LDS between steps and only the records travel (counter traffic about a tenth, "
+                             "profiles/r02_loop_config2_pmc.json): the fraction says how fast the steps go, not how busy HBM is") if loop_steps > 0 else
+                            "algorithmic bytes = (32 + 8K) B per site + the deposits, per step",
                     "deposits_per_step": dep_per_step, "kernels_per_step": len(kern) if loop_steps == 0 else 1.0 / loop_steps,
                     "steps_per_launch": loop_steps if loop_steps > 0 else 1}
         roof = dict(roof or {}, **{"hbm_copy_GBps": hbm_copy})
