@@ -5,11 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path (mean field + occupancy at every particle -> rates -> Philox draw -> commit)
-over all N particles, in the formulation --method selects: "lattice" (default: the reference's histogram ->
-smoothing -> gather, the smoothed histograms kept incrementally on the L sites) or "pairs" (all-pairs tile kernel).  Workload: N=100000 particles on L=200000 sites, K=1, reflecting walls,
-sigma=0.005 (sigma_g=1000, 4001 taps), beta=0.7, rate_active=5, rate_diffusion=0.02, dt=0.0125,
-uniform-in-box synthetic initial condition, float64.  With --gpus N the particles are sharded by index
-(strong scaling of ONE system: the per-step all-gather carries 1 byte per particle).
+over all N particles, in the formulation --method selects: "tiles" (= "auto", the default: the reference's histogram ->
+smoothing -> gather kept incrementally on the L sites, the whole step in ONE kernel over a site-centric state; the steps of
+a call run inside one launch, the resident loop, where the grid of tiles fits the device), "lattice" (the same field, three
+kernels, particle-indexed state) or "pairs" (all-pairs tile kernel).  Workload: N=100000 particles on
+L=200000 sites, K=1, reflecting walls, sigma=0.005 (sigma_g=1000, 4001 taps), beta=0.7, rate_active=5, rate_diffusion=0.02,
+dt=0.0125, uniform-in-box synthetic initial condition, float64.  With --gpus N ONE system is sharded by SITE RANGE over
+the ranks (strong scaling, BASELINE config 3): every k-th step each rank sends its boundary state to its two neighbour
+ranks -- by peer stores into IPC-mapped buffers ("exchange": "ipc-peer"), else by ncclSend / ncclRecv ("rccl");
+--workload config4 deals independent ensembles to the ranks instead (weak scaling, no data-path communication).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -387,7 +391,37 @@ def main():
         h.set_state(pos, spin)
         forced = os.environ.get("APS_BENCH_EXCHANGE", "")
         run, path = None, ""
-        if forced in ("", "rccl"):
+        if site_shards and forced in ("", "ipc-peer"):
+            # preferred: peer stores into the neighbour's IPC-mapped landing buffer (include/aps.h: aps_ipc_export / aps_ipc_connect);
+            # the 256-byte blobs go round over gloo once
+            ok, blobs = True, [None] * world
+            try:
+                mine_blob = h.ipc_export()
+            except Exception as exc:                         # noqa: BLE001
+                ok, mine_blob = False, None
+                print(f"[rank {rank}] peer-store transport unavailable ({exc})", file=sys.stderr)
+            dist.all_gather_object(blobs, mine_blob)
+            if all_agree(ok and all(b is not None for b in blobs)):
+                try:
+                    h.ipc_connect(blobs[rank - 1] if rank > 0 else None, blobs[rank + 1] if rank + 1 < world else None)
+                except Exception as exc:                     # noqa: BLE001
+                    ok = False
+                    print(f"[rank {rank}] peer-store transport unavailable ({exc})", file=sys.stderr)
+                if all_agree(ok):
+                    try:
+                        h.step(max(1, h.halo_info()[0]))     # up to the first exchange: the mapping works in both directions
+                    except Exception as exc:                 # noqa: BLE001
+                        ok = False
+                        print(f"[rank {rank}] peer-store exchange failed ({exc})", file=sys.stderr)
+                    if all_agree(ok):
+                        run, exchange, ranks_seen = h.step, "ipc-peer", len([b for b in blobs if b is not None])
+                        path = "peer stores into the neighbour ranks' IPC-mapped landing buffers + one arrival word per block, inside aps_step"
+                if run is None:                              # a half-connected handle is of no use: start over for the next transport
+                    dist.barrier()
+                    h.close()
+                    h = make_handle(capi, w, device=device, rank=rank, world=world, method="tiles")
+                    h.set_state(pos, spin)
+        if run is None and forced in ("", "rccl"):
             ids = [None]
             if rank == 0:                                    # a failure here must not unbalance the collectives below
                 try:
@@ -495,6 +529,7 @@ def main():
         extra = {"repeats": len(times), "repeats_ms_per_step": [t / args.steps * 1e3 for t in times], "graph_replay": False}
         # consistency across ranks: site shards -> every particle is owned by exactly one rank; index shards -> same state everywhere
         p, s, b, a = h.get_state()
+        dist.barrier()                                       # (peer stores: no rank frees its landing buffers before all are done)
         if site_shards:
             owned = torch.tensor([int((a != 2).sum()), int(p[a == 1].astype(np.int64).sum())], dtype=torch.int64)
             dist.all_reduce(owned, op=dist.ReduceOp.SUM)

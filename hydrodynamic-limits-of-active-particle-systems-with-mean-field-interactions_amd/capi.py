@@ -126,6 +126,9 @@ def load():
         "aps_halo_info": (C.c_int, [vp, P(i32), P(i32), P(i32)]),
         "aps_comm_selftest": (C.c_int, [vp, i64]),
         "aps_halo_sizes": (C.c_int, [vp, P(i64), P(i64)]),
+        "aps_ipc_export": (C.c_int, [vp, vp]),
+        "aps_ipc_connect": (C.c_int, [vp, vp, vp]),
+        "aps_exchange_kind": (C.c_int, [vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -285,6 +288,23 @@ class Handle:
     def comm_selftest(self, nbytes=1 << 16):
         """nbytes from this rank to itself through the halo's transport calls (ncclSend / ncclRecv in one group)."""
         self._ck(self.lib.aps_comm_selftest(self._h, int(nbytes)))
+
+    def ipc_export(self) -> bytes:
+        """Peer-store transport of the halo, step 1: allocate this rank's landing buffers and return the 256-byte blob its two
+        neighbour ranks need (any transport may carry it: torch.distributed gloo, a pipe, a file)."""
+        buf = (C.c_uint8 * 256)()
+        self._ck(self.lib.aps_ipc_export(self._h, C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def ipc_connect(self, left_blob, right_blob):
+        """Step 2: map the neighbours' landing buffers (None where a reflecting wall is the neighbour); afterwards `step` moves
+        the halo itself -- packed blocks stored straight into the neighbour's memory, one arrival word per block."""
+        keep = [None if b is None else (C.c_uint8 * 256).from_buffer_copy(b) for b in (left_blob, right_blob)]
+        self._ck(self.lib.aps_ipc_connect(self._h, *[None if k is None else C.cast(k, C.c_void_p) for k in keep]))
+
+    def exchange_kind(self):
+        """How `step` moves the halo of a sharded handle: "ipc-peer", "rccl" or "none" (the caller moves it)."""
+        return {0: "none", 1: "rccl", 2: "ipc-peer"}[self.lib.aps_exchange_kind(self._h)]
 
     def comm_ranks(self):
         n = C.c_int32()

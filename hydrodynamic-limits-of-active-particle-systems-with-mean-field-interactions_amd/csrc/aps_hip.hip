@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
@@ -1210,6 +1211,80 @@ __global__ __launch_bounds__(256) void halo_move(const HaloSegD *__restrict__ se
     }
 }
 
+// ---- the same halo by PEER STORES (aps_ipc_export / aps_ipc_connect): a rank writes its packed block straight into the
+// landing buffer of its neighbour rank -- device memory of the neighbour's process, mapped here through a HIP IPC handle
+// (over xGMI when the neighbour is another GPU) -- followed by ONE arrival word carrying the exchange's tag; the neighbour's
+// pull kernel waits for the tag and unpacks.  No RCCL kernel, no host call per exchange, nothing but two small launches on
+// the handle's stream.  Landing buffers and arrival words are double buffered by exchange parity: a rank can only start
+// exchange m after it has pulled exchange m - 1, which its neighbour pushed after pulling m - 2 from the buffer m will reuse.
+struct HaloPushArgs {
+    const HaloSegD *segs[2];              // [side]: this rank's first / last block
+    int nseg[2];
+    char *dst[2];                         // the neighbour's landing buffer for that block (peer memory)
+    unsigned long long *flag[2];          // its arrival word
+    unsigned *done;                       // [2] local completion counters (zero between launches)
+    unsigned tag;
+};
+__global__ __launch_bounds__(256) void halo_push(const HaloPushArgs a, char *a0, char *a1, char *a2, char *a3) {
+    const int nb0 = a.nseg[0] * HALO_BPS;
+    const int side = (int)blockIdx.x < nb0 ? 0 : 1;
+    const int bl = (int)blockIdx.x - (side ? nb0 : 0);
+    const HaloSegD g = a.segs[side][bl / HALO_BPS];
+    const char *arr = (g.array == 0 ? a0 : g.array == 1 ? a1 : g.array == 2 ? a2 : a3) + g.arr_off;
+    char *m = a.dst[side] + g.msg_off;
+    const unsigned words = g.bytes >> 2;
+    for (unsigned i = (unsigned)(bl % HALO_BPS) * 256 + threadIdx.x; i < words; i += HALO_BPS * 256)
+        reinterpret_cast<uint32_t *>(m)[i] = reinterpret_cast<const uint32_t *>(arr)[i];
+    __threadfence_system();               // this thread's stores have reached the neighbour's memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned nblk = (unsigned)a.nseg[side] * HALO_BPS;
+        if (atomicAdd(&a.done[side], 1u) == nblk - 1u) {          // the last block of this message: everything of it has landed
+            __hip_atomic_store(&a.done[side], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(a.flag[side], (unsigned long long)a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+struct HaloPullArgs {
+    const HaloSegD *segs[2];              // [from_side]: the right neighbour's first block / the left neighbour's last
+    int nseg[2];
+    const char *src[2];                   // this rank's landing buffers
+    const unsigned long long *flag[2];
+    unsigned tag;
+    unsigned long long timeout_ticks;     // of the 100 MHz clock
+    unsigned *err_host;                   // host-mapped: a wait ran out
+};
+__global__ __launch_bounds__(256) void halo_pull(const HaloPullArgs a, char *a0, char *a1, char *a2, char *a3) {
+    __shared__ int ok_s;
+    const int nb0 = a.nseg[0] * HALO_BPS;
+    const int side = (int)blockIdx.x < nb0 ? 0 : 1;
+    const int bl = (int)blockIdx.x - (side ? nb0 : 0);
+    if (threadIdx.x == 0) {               // bounded wait for the neighbour's arrival word
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 0;
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned long long v = __hip_atomic_load(a.flag[side], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)((unsigned)v - a.tag) >= 0) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) break;
+        }
+        if (!ok) __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok_s = ok;
+    }
+    __syncthreads();
+    if (!ok_s) return;
+    __threadfence_system();
+    const HaloSegD g = a.segs[side][bl / HALO_BPS];
+    char *arr = (g.array == 0 ? a0 : g.array == 1 ? a1 : g.array == 2 ? a2 : a3) + g.arr_off;
+    const char *m = a.src[side] + g.msg_off;
+    const unsigned words = g.bytes >> 2;
+    // (system-scope loads: written by another device / process, never served from this device's caches)
+    for (unsigned i = (unsigned)(bl % HALO_BPS) * 256 + threadIdx.x; i < words; i += HALO_BPS * 256)
+        reinterpret_cast<uint32_t *>(arr)[i] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(m) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // streaming copy, 16 bytes per lane: the HBM ceiling this box reaches in practice (bench.py quotes it beside the 8 TB/s spec)
 __global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
     // four independent 16-byte loads per thread in flight, then the four stores: one workgroup = 16 KB
@@ -1402,6 +1477,7 @@ struct aps_handle {
     int loop_wanted = 1;                                       // aps_set_resident_loop
     uint32_t loop_tag = 0;                                     // tags handed out so far
     int64_t last_loop_steps = 0;
+    unsigned loop_stall = 0u;                                  // APS_LOOP_TEST_STALL word currently in d_abort[1]
     uint32_t *loop_dbg = nullptr; int loop_dbg_n = 0;          // APS_LOOP_DEBUG builds
     bool loop_timed = false;                                   // the next loop launch carries start/stop events (aps_step_loop_timed)
     hipEvent_t loop_ev[2] = {nullptr, nullptr};
@@ -1422,6 +1498,15 @@ struct aps_handle {
     HaloSegD *d_halo_seg_send[2] = {nullptr, nullptr}, *d_halo_seg_recv[2] = {nullptr, nullptr};
     int halo_nseg_send[2] = {0, 0}, halo_nseg_recv[2] = {0, 0};
     size_t halo_bytes_send[2] = {0, 0}, halo_bytes_recv[2] = {0, 0};
+    // peer-store transport of the halo (aps_ipc_export / aps_ipc_connect)
+    char *ipc_land = nullptr;                  // this rank's landing allocation: arrival words, then [parity][from_side] buffers
+    size_t ipc_land_bytes = 0, ipc_land_off[2][2] = {{0, 0}, {0, 0}};
+    char *ipc_peer[2] = {nullptr, nullptr};    // [0] the left neighbour's landing allocation as mapped here, [1] the right one's
+    void *ipc_opened[2] = {nullptr, nullptr};  // what hipIpcOpenMemHandle returned (closed in aps_destroy)
+    size_t ipc_peer_off[2][2] = {{0, 0}, {0, 0}};   // [side][parity]: where this rank's block `side` lands in that neighbour
+    unsigned *d_ipc_done = nullptr, *h_ipc_err = nullptr, *h_ipc_err_dev = nullptr;
+    uint32_t ipc_seq = 0;                      // exchanges made so far
+    bool ipc_on = false;
     int ts_RS = 2, ts_own = 124, ts_ntile = 0, ts_dcap = 0;
     bool ts_table_in_lds = true;
     bool slots_dirty = false;                  // the particle-indexed arrays lag behind the cells
@@ -1738,6 +1823,14 @@ int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, i
 // (re)build W, S on all sites from the particles (state upload; afterwards the field is kept incrementally)
 int ensure_tiles(aps_handle *h);
 
+// the device step words {even, odd} for the handle's step index (step n reads word n & 1 and writes n + 1 into the other)
+int upload_stepw(aps_handle *h) {
+    const unsigned long long sw[2] = {(unsigned long long)(h->step & 1 ? h->step - 1 : h->step), (unsigned long long)(h->step & 1 ? h->step : h->step + 1)};
+    HIP_TRY(h, hipMemcpyAsync(h->d_stepw, sw, sizeof(sw), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return APS_OK;
+}
+
 int ensure_lattice(aps_handle *h) {
     if (h->method == APS_METHOD_TILES) return ensure_tiles(h);
     if (h->method != APS_METHOD_LATTICE) return APS_OK;
@@ -2018,6 +2111,20 @@ int launch_tile_loop(aps_handle *h, int64_t n) {
     h->loop_dbg = dbg; h->loop_dbg_n = (int)n;
 #endif
     if (std::getenv("APS_LOOP_TEST_ABORT")) HIP_TRY(h, hipMemsetAsync(h->d_abort, 1, 4, h->stream));   // tests: the call gives up at once
+    {   // tests: "<tile>:<iteration>" -- that tile (of ensemble 0) leaves at the top of that iteration without writing its record and
+        // without raising the give-up word, like a workgroup that never became resident: its neighbours' waits run out mid-loop
+        unsigned stall = 0u;
+        if (const char *env = std::getenv("APS_LOOP_TEST_STALL")) {
+            int st_tile = -1, st_it = 0;
+            if (std::sscanf(env, "%d:%d", &st_tile, &st_it) == 2 && st_tile >= 0 && st_tile < h->ts_ntile && st_it >= 0 && st_it < 0xFFFF)
+                stall = ((unsigned)(st_tile + 1) << 16) | (unsigned)st_it;
+        }
+        if (stall != h->loop_stall) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_abort + 1, &stall, 4, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));       // (the source is a stack variable)
+            h->loop_stall = stall;
+        }
+    }
     const void *fn = tl_kernel(h);
     const size_t lds = tl_lds_layout(h->tlen, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h), h->loop_seg).total;
     const void *table_ptr = h->f32 ? (const void *)h->d_table_i : (const void *)h->d_table;
@@ -2152,6 +2259,42 @@ int halo_exchange_rccl(aps_handle *h) {
     if (nr != ncclSuccess) return fail(h, APS_ERR_HIP, std::string("halo exchange (ncclSend/ncclRecv): ") + g_rccl.GetErrorString(nr));
     if (right >= 0 && (rc = halo_launch(h, 0, true))) return rc;
     if (left >= 0 && (rc = halo_launch(h, 1, true))) return rc;
+    h->halo_got = halo_expected(h);
+    return APS_OK;
+}
+
+// the same exchange by peer stores: one push launch (both blocks), one pull launch (both blocks), nothing else
+int halo_exchange_ipc(aps_handle *h) {
+    int left, right;
+    halo_peers(h, left, right);
+    const int buf = (int)((h->step & 1) ^ 1), par = (int)(h->ipc_seq & 1u);
+    const unsigned tag = h->ipc_seq + 1u;
+    HaloPushArgs pu{};
+    HaloPullArgs pl{};
+    const int peer_of_side[2] = {left, right};
+    for (int side = 0; side < 2; ++side) {
+        if (peer_of_side[side] >= 0 && h->halo_nseg_send[side]) {
+            pu.segs[side] = h->d_halo_seg_send[side]; pu.nseg[side] = h->halo_nseg_send[side];
+            pu.dst[side] = h->ipc_peer[side] + h->ipc_peer_off[side][par];
+            pu.flag[side] = reinterpret_cast<unsigned long long *>(h->ipc_peer[side] + (size_t)(par * 2 + side) * 64);
+        }
+        const int from = side == 0 ? right : left;               // recv[0]: the right neighbour's first block, recv[1]: the left one's last
+        if (from >= 0 && h->halo_nseg_recv[side]) {
+            pl.segs[side] = h->d_halo_seg_recv[side]; pl.nseg[side] = h->halo_nseg_recv[side];
+            pl.src[side] = h->ipc_land + h->ipc_land_off[par][side];
+            pl.flag[side] = reinterpret_cast<const unsigned long long *>(h->ipc_land + (size_t)(par * 2 + side) * 64);
+        }
+    }
+    pu.done = h->d_ipc_done; pu.tag = tag;
+    pl.tag = tag; pl.err_host = h->h_ipc_err_dev;
+    pl.timeout_ticks = 20ull * 100000000ull;                     // 20 s: the neighbour may be far behind (another process)
+    if (const char *env = std::getenv("APS_HALO_TIMEOUT_MS")) pl.timeout_ticks = (unsigned long long)std::max(1, std::atoi(env)) * 100000ull;
+    char *a0 = halo_array(h, 0, buf), *a1 = halo_array(h, 1, buf), *a2 = halo_array(h, 2, buf), *a3 = halo_array(h, 3, buf);
+    const unsigned nbu = (unsigned)(pu.nseg[0] + pu.nseg[1]) * HALO_BPS, nbl = (unsigned)(pl.nseg[0] + pl.nseg[1]) * HALO_BPS;
+    if (nbu) hipLaunchKernelGGL(halo_push, dim3(nbu), dim3(256), 0, h->stream, pu, a0, a1, a2, a3);
+    if (nbl) hipLaunchKernelGGL(halo_pull, dim3(nbl), dim3(256), 0, h->stream, pl, a0, a1, a2, a3);
+    HIP_TRY(h, hipGetLastError());
+    h->ipc_seq += 1u;
     h->halo_got = halo_expected(h);
     return APS_OK;
 }
@@ -2496,6 +2639,10 @@ void aps_destroy(aps_handle *h) {
     for (int b = 0; b < 2; ++b)
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
+    for (void *q : h->ipc_opened) if (q) (void)hipIpcCloseMemHandle(q);
+    if (h->ipc_land) (void)hipFree(h->ipc_land);
+    if (h->d_ipc_done) (void)hipFree(h->d_ipc_done);
+    if (h->h_ipc_err) (void)hipHostFree(h->h_ipc_err);
     for (hipEvent_t ev : h->loop_ev) if (ev) (void)hipEventDestroy(ev);
     for (void *q : {(void *)h->d_xrec, (void *)h->d_abort}) if (q) (void)hipFree(q);
     for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)h->d_wsi[1],
@@ -2677,7 +2824,9 @@ void drop_graphs(aps_handle *h) {
 int one_step(aps_handle *h) {
     int rc;
     if ((rc = do_propose(h))) return rc;
-    if (h->comm && is_tiles(h)) {                            // site-range shards: boundary sites and deposit lists to the neighbours
+    if (h->ipc_on && is_tiles(h)) {                          // site-range shards: boundary state to the neighbours, by peer stores
+        if (halo_due(h) && (rc = halo_exchange_ipc(h))) return rc;
+    } else if (h->comm && is_tiles(h)) {                     // the same through ncclSend / ncclRecv
         if (halo_due(h) && (rc = halo_exchange_rccl(h))) return rc;
     } else if (h->comm) {                                    // one in-place all-gather of 1 byte per particle
         const size_t block = (size_t)h->E * (size_t)h->SH;
@@ -2743,8 +2892,8 @@ extern "C" {
 int aps_step(aps_handle *h, int64_t nsteps) {
     if (!h) return APS_ERR_ARG;
     if (nsteps < 0) return fail(h, APS_ERR_ARG, "aps_step: nsteps < 0");
-    if (h->world != 1 && !h->comm)
-        return fail(h, APS_ERR_STATE, "aps_step: sharded handle without communicator; call aps_comm_init, or use aps_propose / exchange / aps_commit");
+    if (h->world != 1 && !h->comm && !h->ipc_on)
+        return fail(h, APS_ERR_STATE, "aps_step: sharded handle without transport; call aps_ipc_export / aps_ipc_connect or aps_comm_init, or use aps_propose / exchange / aps_commit");
     if (!all_set(h)) return fail(h, APS_ERR_STATE, "aps_step: upload a state for every ensemble first");
     int rc = ensure_lattice(h);
     if (rc) return rc;
@@ -2779,6 +2928,9 @@ int aps_step(aps_handle *h, int64_t nsteps) {
                     h->h_abort[0] = 0u;
                     h->loop_state = -1;
                     h->loop_why = "a wait ran out (the grid was not resident at once); steps repeated with one launch per step";
+                    // a tile that finished all n iterations before the call was given up has written the step word of the
+                    // final parity -- for an even n that is the word the first repeated step reads: set the pair again
+                    if ((rc = upload_stepw(h))) return rc;
                 } else {
                     h->step += n; s += n; h->last_loop_steps = n;
                     h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true;
@@ -2814,6 +2966,10 @@ int aps_step(aps_handle *h, int64_t nsteps) {
     for (; s < nsteps; ++s, ++h->last_single_steps)
         if ((rc = one_step(h))) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->h_ipc_err && h->h_ipc_err[0]) {
+        h->h_ipc_err[0] = 0u;
+        return fail(h, APS_ERR_STATE, "aps_step: a neighbour rank's halo did not arrive in time (peer-store transport); the state of this handle is incomplete");
+    }
     return APS_OK;
 }
 
@@ -3160,6 +3316,94 @@ int aps_comm_selftest(aps_handle *h, int64_t nbytes) {
     if (got != pat) return fail(h, APS_ERR_HIP, "aps_comm_selftest: received bytes differ from the bytes sent");
     return APS_OK;
 }
+
+// ---- peer-store transport of the halo: export this rank's landing buffers, connect to the neighbours'
+namespace {
+struct IpcBlob {                              // what aps_ipc_export hands out (APS_IPC_BLOB_BYTES = 256)
+    uint32_t magic; int32_t pid, device, rank;
+    uint64_t base, total, recv_bytes[2], land_off[2][2];   // land_off[parity][from_side]
+    hipIpcMemHandle_t handle;
+};
+static_assert(sizeof(IpcBlob) <= 256, "IpcBlob must fit the blob");
+constexpr uint32_t IPC_MAGIC = 0x41505331u;   // "APS1"
+}
+
+int aps_ipc_export(aps_handle *h, uint8_t *blob256) {
+    if (!h || !blob256) return APS_ERR_ARG;
+    if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_ipc_export: not a site-sharded tiles handle");
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    if (!h->ipc_land) {
+        size_t off = 256;                                        // arrival words first: [parity][from_side], 64 bytes apart
+        for (int par = 0; par < 2; ++par)
+            for (int side = 0; side < 2; ++side) { h->ipc_land_off[par][side] = off; off += (h->halo_bytes_recv[side] + 255) / 256 * 256; }
+        h->ipc_land_bytes = off;
+        // fine-grained device memory: written by another device while this one polls it, never cached on the way
+        void *ptr = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&ptr, off, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ptr, off); }
+        if (e != hipSuccess) return fail(h, APS_ERR_HIP, std::string("aps_ipc_export: landing buffer: ") + hipGetErrorString(e));
+        h->ipc_land = static_cast<char *>(ptr);
+        HIP_TRY(h, hipMemset(h->ipc_land, 0, off));
+        int rc;
+        if ((rc = dev_alloc(h, &h->d_ipc_done, 2))) return rc;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_ipc_err), 64, hipHostMallocMapped));
+        h->h_ipc_err[0] = 0u;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->h_ipc_err_dev), h->h_ipc_err, 0));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    IpcBlob b{};
+    b.magic = IPC_MAGIC; b.pid = (int32_t)getpid(); b.device = h->p.device; b.rank = h->rank;
+    b.base = (uint64_t)(uintptr_t)h->ipc_land; b.total = h->ipc_land_bytes;
+    for (int side = 0; side < 2; ++side) b.recv_bytes[side] = h->halo_bytes_recv[side];
+    for (int par = 0; par < 2; ++par) for (int side = 0; side < 2; ++side) b.land_off[par][side] = h->ipc_land_off[par][side];
+    const hipError_t e = hipIpcGetMemHandle(&b.handle, h->ipc_land);
+    if (e != hipSuccess) return fail(h, APS_ERR_HIP, std::string("aps_ipc_export: hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    std::memset(blob256, 0, 256);
+    std::memcpy(blob256, &b, sizeof(b));
+    return APS_OK;
+}
+
+int aps_ipc_connect(aps_handle *h, const uint8_t *left_blob, const uint8_t *right_blob) {
+    if (!h) return APS_ERR_ARG;
+    if (!is_tiles(h) || h->world < 2) return fail(h, APS_ERR_STATE, "aps_ipc_connect: not a site-sharded tiles handle");
+    if (!h->ipc_land) return fail(h, APS_ERR_STATE, "aps_ipc_connect: call aps_ipc_export first");
+    if (h->ipc_on) return fail(h, APS_ERR_STATE, "aps_ipc_connect: already connected");
+    int left, right;
+    halo_peers(h, left, right);
+    const int want[2] = {left, right};
+    const uint8_t *blobs[2] = {left_blob, right_blob};
+    HIP_TRY(h, hipSetDevice(h->p.device));
+    IpcBlob b[2];
+    for (int side = 0; side < 2; ++side) {
+        if (want[side] < 0) continue;
+        if (!blobs[side]) return fail(h, APS_ERR_ARG, "aps_ipc_connect: a neighbour's blob is missing");
+        std::memcpy(&b[side], blobs[side], sizeof(IpcBlob));
+        if (b[side].magic != IPC_MAGIC || b[side].rank != want[side]) return fail(h, APS_ERR_ARG, "aps_ipc_connect: not the blob of that neighbour rank");
+        // this rank's first block (side 0) lands where the LEFT neighbour keeps "the right neighbour's first block" (its recv[0]);
+        // the last block (side 1) where the RIGHT neighbour keeps "the left neighbour's last block" (its recv[1])
+        if (b[side].recv_bytes[side] != h->halo_bytes_send[side]) return fail(h, APS_ERR_ARG, "aps_ipc_connect: the neighbour expects a block of another size (different lattice, tiling or halo interval)");
+    }
+    for (int side = 0; side < 2; ++side) {
+        if (want[side] < 0) continue;
+        if (side == 1 && want[0] == want[1] && h->ipc_peer[0]) { h->ipc_peer[1] = h->ipc_peer[0]; }          // two ranks on a torus: one neighbour
+        else if (b[side].pid == (int32_t)getpid()) h->ipc_peer[side] = reinterpret_cast<char *>((uintptr_t)b[side].base);   // another handle of this process
+        else {
+            int can = 0;
+            if (b[side].device != h->p.device && hipDeviceCanAccessPeer(&can, h->p.device, b[side].device) == hipSuccess && can)
+                if (hipDeviceEnablePeerAccess(b[side].device, 0) != hipSuccess) (void)hipGetLastError();      // (already enabled is fine)
+            void *ptr = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&ptr, b[side].handle, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, APS_ERR_HIP, std::string("aps_ipc_connect: hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
+            h->ipc_opened[side] = ptr;
+            h->ipc_peer[side] = static_cast<char *>(ptr);
+        }
+        for (int par = 0; par < 2; ++par) h->ipc_peer_off[side][par] = (size_t)b[side].land_off[par][side];
+    }
+    h->ipc_on = true;
+    return APS_OK;
+}
+
+int aps_exchange_kind(aps_handle *h) { return !h ? APS_ERR_ARG : (h->ipc_on ? 2 : (h->comm ? 1 : 0)); }
 
 int aps_owned_sites(aps_handle *h, int32_t *lo, int32_t *hi) {
     if (!h) return APS_ERR_ARG;

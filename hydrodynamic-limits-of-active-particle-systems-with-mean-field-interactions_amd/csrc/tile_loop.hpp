@@ -101,11 +101,21 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
     const int tile = (int)blockIdx.x;
     const int own0 = tile * OWN, own_n = min(OWN, L - own0), nfr = own_n + 4;
     const int x0 = own0 - 2;
-    const int x0c = max(x0, 0), x1c = min(x0 + TS - 1, L - 1);
+    // the frame clipped to the lattice AND to its valid positions (own_n + 4 sites: the field beyond them is never used).  With
+    // the valid frame the "deposits of tile B reach tile A" relation is symmetric, (|A - B| - 1) OWN <= Rt + 2, which is what
+    // the two record buffers rely on: two tiles that exchange are never more than one step apart
+    const int x0c = max(x0, 0), x1c = min(x0 + nfr - 1, L - 1);
     const int Rt = a.tlen - 1;
     if (__hip_atomic_load((tl_gu32 *)la.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {        // the call was given up before this workgroup started
         if (t == 0) __hip_atomic_store(la.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
+    }
+    // test hook (APS_LOOP_TEST_STALL, abort_dev[1] = (tile + 1) << 16 | iteration, 0 = none): that tile takes only that many
+    // iterations and leaves without its record -- what a workgroup that never became resident looks like to its neighbours
+    int n_iter = la.nsteps;
+    {
+        const unsigned stall = la.abort_dev[1];
+        if (stall && (int)(stall >> 16) - 1 == tile && e == 0) n_iter = min(n_iter, (int)(stall & 0xFFFFu));
     }
     const uint32_t *__restrict__ cell_e = a.cell_in + (size_t)e * L * K;
     const WS *__restrict__ ws_e = reinterpret_cast<const WS *>(a.ws_in) + (size_t)e * L;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
         b0 = max(0, x0c - Rt - 1) / OWN;
         nbk = min(L - 1, x1c + Rt + 1) / OWN - b0 + 1;
     } else {
-        const int lo = x0 - Rt - 1, hi = x0 + TS - 1 + Rt + 1;
+        const int lo = x0 - Rt - 1, hi = x0 + nfr - 1 + Rt + 1;
         if (hi - lo + 1 >= L) { b0 = 0; nbk = a.ntile; }
         else {
             const int lom = ((lo % L) + L) % L, him = ((hi % L) + L) % L;
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
         if (b >= a.ntile) b -= a.ntile;
         return b;
     };
-    for (int it = 0; it < la.nsteps; ++it) {
+    for (int it = 0; it < n_iter; ++it) {
         const unsigned long long step = la.step0 + (unsigned long long)it;
         const uint32_t tag_in = la.tag0 + (uint32_t)it, tag_out = tag_in + 1u;
         const bool first = it == 0, last = it + 1 == la.nsteps;

@@ -14,15 +14,18 @@ from .particle_system import ParticleSystem, run_batched, run_batched_statistics
 
 
 def sweep_over_betas(beta_values, n_runs_per_beta=10, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
-                     rng_seeds=None, keep_outputs=False, on_device=False, dynamics="sync"):
+                     rng_seeds=None, keep_outputs=False, on_device=False, dynamics=None):
     """Returns a dict with the keys the reference saves (`beta_values, means, stds, ses, D_means, D_ses, m_means,
     m_stds, m_ses, rho_means, rho_ses, block_means, block_ses`, ..._sweep_beta.py:952-968) plus `raw_by_beta`.
     `rng_seeds[b][r]` seeds the initial condition of run r at beta b (None: unseeded, like the reference).
     `on_device=True` evaluates the observables from integer sums taken on the GPU at each observation time
     (run_batched_statistics; needs k_exit = 0) instead of from the M x L arrays of `run()`; `run_kwargs` may then
     only hold T and obs_dt.  `dynamics="exact"` runs the reference's event-by-event dynamics resident on the GPU
-    (gillespie.run_batched_exact / run_batched_exact_statistics) instead of the fixed-dt scheme."""
+    (gillespie.run_batched_exact / run_batched_exact_statistics), `"sync"` the fixed-dt scheme; the default follows
+    ParticleSystem's: exact unless `ps_kwargs` asks for the stepper (`dt` or `mode="sync"`)."""
     ps_kwargs, init_kwargs, run_kwargs = dict(ps_kwargs or {}), dict(init_kwargs or {}), dict(run_kwargs or {})
+    if dynamics is None:
+        dynamics = "sync" if (ps_kwargs.get("dt") is not None or ps_kwargs.get("mode") == "sync") else "exact"
     systems, owner = [], []
     for bi, beta in enumerate(beta_values):
         for r in range(n_runs_per_beta):
@@ -74,7 +77,7 @@ def sweep_beta_ensemble(beta, n_runs=10, ps_kwargs=None, init_kwargs=None, run_k
 
 
 def sweep_over_sigmas(sigma_values, beta_values, n_runs_per_beta=5, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
-                      rng_seeds=None, on_device=False, dynamics="sync"):
+                      rng_seeds=None, on_device=False, dynamics=None):
     """The sigma sweep of PARTICLE_solver_BIOLOGY_EXCLUSION_sweep_beta_2.py:1030-1075: for every interaction range
     `local_kernel_sigma` a whole beta sweep (one GPU handle per sigma: the weight table changes; sigma = 0 selects the global
     mean field, sigma wider than the box the folded table).  Returns {sigma: {"beta", "v_mean", "v_se", "D_mean", "D_se",
@@ -89,7 +92,7 @@ def sweep_over_sigmas(sigma_values, beta_values, n_runs_per_beta=5, ps_kwargs=No
 
 
 def sweep_over_densities(n_part_values, beta_values, n_runs_per_beta=4, ps_kwargs=None, init_kwargs=None, run_kwargs=None,
-                         rng_seeds=None, on_device=False, dynamics="sync"):
+                         rng_seeds=None, on_device=False, dynamics=None):
     """The density x beta double sweep of PARTICLE_solver_BIOLOGY_EXCLUSION_double_sweep.py:851-861
     (`list_N_part = np.linspace(50, 950, 19)`: N arrives as a float there and is used as an integer): one batched beta sweep
     per particle number.  Returns a list of the per-N sweep dictionaries (keys of `sweep_over_betas`) with "N_part" added;

@@ -2,16 +2,19 @@
 MI355X stepper.  Same constructor keywords (ref :16-39), same attributes, same `run()` result
 dictionary (ref :542-557); the time loop runs in HIP kernels behind the C ABI of include/aps.h.
 
-Differences that are part of the design:
-  * time advances in fixed steps `dt` (synchronous scheme) instead of one Gillespie event at a time;
-    `dt` defaults to 0.1 / (largest possible total rate of one particle);
-  * randomness inside `run` comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng.random()` right
-    after the initial condition, so a seeded `rng` still makes the whole run reproducible);
-  * a custom `flip_rate_fn` (a Python callable) is honoured by `mode="gillespie"` only; the device modes evaluate the
-    Curie-Weiss rate exp(-beta*sigma*m) themselves and refuse a callable;
-  * `mode="gillespie"` (or calling `step_gillespie` yourself) runs the reference's exact one-event-per-iteration
-    loop instead, with the m-field and the rate vectors of every event computed on the GPU and the event drawn
-    from `rng` in the reference's call order.
+Which dynamics `run()` integrates (`mode`):
+  * default (no `mode`, no `dt` keyword -- an unchanged reference driver): `"gillespie_gpu"`, the reference's own exact
+    one-event-per-iteration loop (ref :511-516, :358-362) resident on the GPU; statistically identical to the reference
+    (fixture G4, no bias allowance).  With a custom `flip_rate_fn` the default is `"gillespie"` (below);
+  * `mode="sync"` (also chosen when the caller passes `dt`): time advances in fixed steps `dt` (synchronous scheme, first
+    order in `dt`: -2 % drift bias at dt = 0.0125; `dt` defaults to 0.1 / (largest possible total rate of one particle)) --
+    the high-throughput stepper behind aps_step that BASELINE's particle-steps/s metric is quoted on;
+  * `mode="gillespie"` (or calling `step_gillespie` yourself): the exact loop with the m-field and the rate vectors of every
+    event computed on the GPU and the event drawn from `rng` in the reference's call order: reproduces the reference's
+    seeded trajectories bit for bit, a custom `flip_rate_fn` (a Python callable) included.
+Randomness of the device modes comes from Philox4x32-10 keyed by `seed` (default: drawn from `rng.random()` right after the
+initial condition, so a seeded `rng` still makes the whole run reproducible).  `m_local_list[k]` is the field of the observed
+state (the reference stores the field from before the last event, ref :525).
 There is no CPU fallback: without libaps_hip.so or without a GPU, construction of the stepper raises.
 """
 from __future__ import annotations
@@ -31,7 +34,7 @@ class ParticleSystem:
                  site_capacity=1, crowding_suppresses_rates=False, k_on=0.1, k_off=0.01,
                  suppress_flip_when_bound=True, k_exit=0,
                  # extensions (all optional, after the reference's keywords)
-                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode="sync", method="auto", fp32=False):
+                 dt=None, seed=None, device=0, sort_by_site=True, ensemble=0, mode=None, method="auto", fp32=False):
         self.L = int(L)
         self.xlim = xlim
         self.K = int(site_capacity)
@@ -84,6 +87,8 @@ class ParticleSystem:
         self.device = int(device)
         self.sort_by_site = bool(sort_by_site)
         self.ensemble = int(ensemble)          # Philox counter word 3 (independent streams under one seed)
+        if mode is None:                       # an unchanged driver gets the reference's dynamics (ref :511-516, :358-362)
+            mode = "sync" if dt is not None else ("gillespie" if flip_rate_fn is not None else "gillespie_gpu")
         if mode not in ("sync", "gillespie", "gillespie_gpu"):
             raise ValueError("mode must be 'sync' (fixed-dt stepper), 'gillespie' (one exact event per iteration, drawn "
                              "from rng on the host) or 'gillespie_gpu' (the exact event loop resident on the GPU)")

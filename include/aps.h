@@ -47,7 +47,8 @@ typedef struct aps_params {
     const double *beta;         /* [n_ensembles]                                     ref :51 */
     const uint8_t *anchor_mask; /* [L] is_anchor_site, or NULL for none              ref :88-104 */
     int32_t device;             /* HIP device ordinal */
-    int32_t rank, world;        /* particle-index shard of this handle (world = 1: everything) */
+    int32_t rank, world;        /* shard of this handle, world = 1: everything.  TILES: the rank's contiguous range of site tiles
+                                   (aps_owned_sites); LATTICE / PAIRS: its block of particle slots */
     int32_t sort_by_site;       /* 1: keep particles ordered by site internally (tile culling) */
     int32_t ensemble_base;      /* Philox counter word 3 of local ensemble e is ensemble_base + e */
     int32_t method;             /* APS_METHOD_*: which formulation of the mean field the stepper uses */
@@ -69,7 +70,9 @@ typedef struct aps_params {
  *            accepted events of each step; site occupancy (ref :248-252) likewise
  *   TILES    the LATTICE formulation with a site-centric state (one word per particle slot of a site) and the whole
  *            step -- field update, rates, draws, exclusion, state update -- in ONE kernel over site tiles; same bits
- *   AUTO     TILES for single-GPU handles, else LATTICE (PAIRS if the deposit lists would exceed 16 GB) */
+ *   AUTO     world = 1: TILES (LATTICE once the binary64 state exceeds 512 MB, the streaming regime); world > 1: LATTICE with
+ *            particle-index shards -- site-range shards are chosen by asking for TILES (bench.py does, and falls back when the
+ *            table's reach does not fit the ranks' ranges); PAIRS if the deposit lists would exceed 16 GB */
 #define APS_METHOD_AUTO 0
 #define APS_METHOD_PAIRS 1
 #define APS_METHOD_LATTICE 2
@@ -155,6 +158,20 @@ int aps_halo_info(aps_handle *h, int32_t *interval, int32_t *age, int32_t *due);
 /* Byte counts of the four blocks: send_bytes[0] / [1] = this rank's first / last block (0: no neighbour on that side),
  * recv_bytes[0] = the RIGHT neighbour's first block, recv_bytes[1] = the LEFT neighbour's last block. */
 int aps_halo_sizes(aps_handle *h, int64_t send_bytes[2], int64_t recv_bytes[2]);
+
+/* The halo of site-sharded TILES handles by PEER STORES, the preferred transport inside aps_step: every rank exports its landing
+ * buffers (aps_ipc_export: device memory + a HIP IPC handle, described by a 256-byte blob that the caller hands to the two
+ * neighbour ranks by any means), maps its neighbours' (aps_ipc_connect; left / right blob, NULL where a reflecting wall is the
+ * neighbour; handles of one process are connected by address) and from then on aps_step, after the kernel of a due step,
+ * launches ONE push kernel that stores this rank's two packed blocks straight into the neighbours' landing buffers (over xGMI
+ * between GPUs) followed by one arrival word each, and ONE pull kernel that waits (bounded: 20 s, APS_HALO_TIMEOUT_MS) for the
+ * neighbours' arrival words and unpacks -- no RCCL kernel, no host call, no host synchronisation per exchange.  Landing buffers
+ * are double buffered by exchange parity.  All ranks must call aps_step with the same step counts; a halo that does not arrive
+ * makes aps_step return APS_ERR_STATE.  aps_exchange_kind: 0 the caller moves the halo, 1 ncclSend / ncclRecv, 2 peer stores. */
+#define APS_IPC_BLOB_BYTES 256
+int aps_ipc_export(aps_handle *h, uint8_t *blob256);
+int aps_ipc_connect(aps_handle *h, const uint8_t *left_blob256, const uint8_t *right_blob256);
+int aps_exchange_kind(aps_handle *h);
 
 /* Number of ranks the communicator of this handle actually spans (ncclCommCount): what a bench line reports as
  * evidence that the exchange ran between that many processes. */

@@ -47,8 +47,12 @@ def test_drop_in_module_and_loud_failure_without_gpu(capi):
     assert ps.L == 100 and ps.dx == 0.01
     pos, sigma = ps.init_particles()
     assert pos.dtype == np.int64 and sigma.dtype == np.int8 and len(np.unique(pos)) == 10
-    with pytest.raises(NotImplementedError, match="gillespie"):      # a callable needs the host event loop
-        ParticleSystem(L=10, xlim=1, rate_diffusion=0, rate_active=1, beta=1, flip_rate_fn=lambda s, m: s)
+    # default dynamics = the reference's: the exact event loop on the GPU; the fixed-dt stepper when the caller passes dt or mode;
+    # a callable flip rate selects the exact loop with host draws
+    assert ps.mode == "gillespie_gpu"
+    assert ParticleSystem(L=100, xlim=1, rate_diffusion=0.1, rate_active=1, beta=0.5, N=10, dt=0.01).mode == "sync"
+    assert ParticleSystem(L=100, xlim=1, rate_diffusion=0.1, rate_active=1, beta=0.5, N=10, mode="sync").mode == "sync"
+    assert ParticleSystem(L=10, xlim=1, rate_diffusion=0, rate_active=1, beta=1, flip_rate_fn=lambda s, m: s).mode == "gillespie"
     assert ParticleSystem(L=10, xlim=1, rate_diffusion=0, rate_active=1, beta=1, flip_rate_fn=lambda s, m: s, mode="gillespie").flip_rate_fn
     if capi.device_count() == 0:
         with pytest.raises(capi.ApsError):

@@ -140,6 +140,30 @@ def test_exact_loop_statistics_match_reference_ensemble(gil, golden):
             assert np.all(diff <= 4.5 * se + 1e-12), (case["beta"], key, float(np.max(diff / (se + 1e-300))))
 
 
+def test_default_constructed_run_is_the_reference_dynamics(golden):
+    """The drop-in default: ParticleSystem(...) with the reference's keywords only (no mode, no dt, no seed) runs the exact event
+    loop (PARTICLE_solver_CLASS.py:511-516, :358-362) on the GPU; 16 plain `ps.run()` calls per beta against the 32 seeded
+    reference runs per beta of fixture G4: 4 sigma, NO bias term (the fixed-dt stepper needs one, tests/test_sync_statistics.py)."""
+    from PARTICLE_solver_CLASS import ParticleSystem
+    g = golden("g4_ensemble_stats.npz")
+    ctor, run, stride = g.meta["ctor"], g.meta["run"], g.meta["stride"]
+    for bi, case in enumerate(g.meta["cases"]):
+        outs = []
+        for r in range(16):
+            ps = ParticleSystem(beta=case["beta"], rng=np.random.default_rng(777000 + 100 * bi + r), **ctor)
+            assert ps.mode == "gillespie_gpu"
+            outs.append(ps.run(T=run["T"], obs_dt=run["obs_dt"]))
+            assert ps.n_events > 1000 and outs[-1]["pos_list"][-1] is not None
+        dx = 1.0 / ctor["L"] * ctor.get("xlim", 1.0)
+        ours = dict(com=np.stack([np.array([p.mean() for p in o["pos_list"]])[::stride] * dx for o in outs]),
+                    m=np.stack([o["m_global"][::stride] for o in outs]))
+        for key, ref_key in (("com", "com"), ("m", "m_ts")):
+            a, b = ours[key], g[f"b{bi}_{ref_key}"]
+            se = np.sqrt(a.var(axis=0, ddof=1) / len(a) + b.var(axis=0, ddof=1) / len(b))
+            diff = np.abs(a.mean(axis=0) - b.mean(axis=0))
+            assert np.all(diff <= 4.0 * se + 1e-12), (case["beta"], key, float(np.max(diff / (se + 1e-300))))
+
+
 def test_scalar_sums_equal_numpy_on_recorded_states(gil):
     rng = np.random.default_rng(5)
     L, K, N = 300, 2, 260

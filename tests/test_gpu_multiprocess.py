@@ -28,11 +28,11 @@ def _case():
     return par, pos, spin
 
 
-def _handle(capi, par, n, method, rank=0, world=1):
+def _handle(capi, par, n, method, rank=0, world=1, **kw):
     return capi.Handle(L=par.L, K=par.K, periodic=par.periodic, sigma_grid=par.sigma_grid, rate_diffusion=par.rate_diffusion,
                        rate_active=par.rate_active, beta=[par.beta], dt=0.03, seed=99, n_particles=n, minus_anchor=par.minus_anchor,
                        immobilize=par.immobilize_when_anchored, suppress_flip=par.suppress_flip_when_bound, k_on=par.k_on,
-                       k_off=par.k_off, k_exit=par.k_exit, anchor_mask=par.is_anchor_site, rank=rank, world=world, method=method)
+                       k_off=par.k_off, k_exit=par.k_exit, anchor_mask=par.is_anchor_site, rank=rank, world=world, method=method, **kw)
 
 
 def _worker(rank, world, port, nsteps, method, out_dir):
@@ -112,9 +112,22 @@ def _tiles_case():
     return par, pos, spin
 
 
-def _tiles_worker(rank, world, port, nsteps, out_dir):
-    """One REAL process per rank, each with a site-sharded tiles handle (all on device 0); the halo blocks travel as bytes
-    over gloo (aps_halo_pack / aps_halo_unpack) -- the same blocks ncclSend / ncclRecv move between GPUs in aps_step."""
+def _config3_case():
+    """BASELINE config 3 = config 2's system (N = 1e5, L = 2e5, K = 1, 4001-tap table) sharded by site range."""
+    from oracle.gillespie_numpy import LatticeGasParams
+    par = LatticeGasParams.from_kwargs(L=200000, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7, scale_rates=False,
+                                       local_kernel_sigma=0.005, site_capacity=1)
+    rng = np.random.default_rng(3)
+    pos = rng.choice(200000, size=100000, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=100000)
+    return par, pos, spin
+
+
+def _tiles_worker(rank, world, port, nsteps, out_dir, transport="gloo-bytes", interval=0, case="small"):
+    """One REAL process per rank, each with a site-sharded tiles handle (all on device 0).  transport "gloo-bytes": the halo
+    blocks travel as bytes over gloo (aps_halo_pack / aps_halo_unpack) -- the same blocks ncclSend / ncclRecv move between GPUs
+    in aps_step.  transport "ipc": the production path -- every rank exports its landing buffers (HIP IPC handle), the blobs go
+    round over gloo once, and aps_step moves the halo itself by peer stores into the neighbour PROCESS's device memory."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -123,11 +136,22 @@ def _tiles_worker(rank, world, port, nsteps, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         capi = importlib.import_module(PKG + ".capi")
-        par, pos, spin = _tiles_case()
-        h = _handle(capi, par, len(pos), "tiles", rank, world)
+        par, pos, spin = _tiles_case() if case == "small" else _config3_case()
+        h = _handle(capi, par, len(pos), "tiles", rank, world, halo_interval=interval)
         h.set_state(pos, spin)
         left, right = rank - 1, rank + 1                       # reflecting walls: the end ranks have one neighbour
-        for _ in range(nsteps):
+        if transport == "ipc":
+            blobs = [None] * world
+            dist.all_gather_object(blobs, h.ipc_export())
+            h.ipc_connect(blobs[left] if left >= 0 else None, blobs[right] if right < world else None)
+            assert h.exchange_kind() == "ipc-peer"
+            done = 0
+            for n in (1, 6, 2, 25, nsteps):                    # calls of various lengths, ending between exchanges too
+                n = min(n, nsteps - done)
+                h.step(n)
+                done += n
+            assert done == nsteps and h.time()[1] == nsteps
+        for _ in range(nsteps if transport != "ipc" else 0):
             h.propose()
             if not h.halo_info()[2]:                           # the ghost zone still covers this step: no exchange
                 h.commit()
@@ -154,20 +178,25 @@ def _tiles_worker(rank, world, port, nsteps, out_dir):
         p, s, b, a = h.get_state()
         lo, hi = h.owned_sites()
         W, S, occ = h.get_lattice()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=p, spin=s, bound=b, alive=a, exits=h.exits(), lo=lo, hi=hi, W=W, S=S, occ=occ)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=p, spin=s, bound=b, alive=a, exits=h.exits(), lo=lo, hi=hi, W=W, S=S, occ=occ,
+                 interval=h.halo_info()[0])
+        dist.barrier()                                         # nobody frees a landing buffer a neighbour may still be writing to
         h.close()
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport,interval", [("gloo-bytes", 0), ("ipc", 1), ("ipc", 0)], ids=["gloo-bytes", "ipc-k1", "ipc-kauto"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_site_sharded_tiles_across_processes(tmp_path, world):
+def test_site_sharded_tiles_across_processes(tmp_path, world, transport, interval):
+    """`world` processes on one GPU, one site range each; "ipc": stepping through aps_step with the halo moved by peer stores
+    into the neighbour process's IPC-mapped landing buffer (halo interval 1 and the library's choice)."""
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     capi = importlib.import_module(PKG + ".capi")
     nsteps = 50
-    port = 31200 + (os.getpid() % 1500) + 11 * world
-    mp.spawn(_tiles_worker, args=(world, port, nsteps, str(tmp_path)), nprocs=world, join=True)
+    port = 31200 + (os.getpid() % 1500) + 11 * world + (101 if transport == "ipc" else 0) + 53 * interval
+    mp.spawn(_tiles_worker, args=(world, port, nsteps, str(tmp_path), transport, interval), nprocs=world, join=True)
     par, pos, spin = _tiles_case()
     single = _handle(capi, par, len(pos), "tiles")
     try:
@@ -196,3 +225,40 @@ def test_site_sharded_tiles_across_processes(tmp_path, world):
         assert np.array_equal(m, w)
     ex = np.concatenate(exits)
     assert np.array_equal(ex[np.lexsort((ex[:, 2], ex[:, 0]))], want_exits)
+
+
+def test_config3_workload_across_processes_by_peer_stores(tmp_path):
+    """BASELINE config 3's workload (N = 1e5, L = 2e5) as four site ranges in four PROCESSES on one GPU, stepped through aps_step
+    with the peer-store transport and the library's halo interval (a box allows six processes on its card; the eight-way split
+    of the same workload runs in one process with aps_halo_copy: tests/test_gpu_parity.py).  Merged state, {W, S, occupancy} on
+    the own sites and ownership equal the single handle's after 50 steps."""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    capi = importlib.import_module(PKG + ".capi")
+    world, nsteps = 4, 50
+    port = 33100 + (os.getpid() % 1500)
+    mp.spawn(_tiles_worker, args=(world, port, nsteps, str(tmp_path), "ipc", 0, "config3"), nprocs=world, join=True)
+    par, pos, spin = _config3_case()
+    single = _handle(capi, par, len(pos), "tiles")
+    try:
+        single.set_state(pos, spin)
+        single.step(nsteps)
+        want = single.get_state()
+        Ws, Ss, occs = single.get_lattice()
+    finally:
+        single.close()
+    n = len(pos)
+    seen = np.zeros(n, int)
+    merged = [np.zeros(n, np.int32), np.zeros(n, np.int8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert int(got["interval"]) >= 2                         # a ghost zone: exchanges every k-th step only
+        mine = got["alive"] != 2
+        seen += mine
+        for m, key in zip(merged, ("pos", "spin", "bound", "alive")):
+            m[mine] = got[key][mine]
+        lo, hi = int(got["lo"]), int(got["hi"])
+        assert np.array_equal(got["W"][lo:hi], Ws[lo:hi]) and np.array_equal(got["S"][lo:hi], Ss[lo:hi]) and np.array_equal(got["occ"][lo:hi], occs[lo:hi])
+    assert np.array_equal(seen, np.ones(n, int))
+    for m, w in zip(merged, want):
+        assert np.array_equal(m, w)

@@ -725,6 +725,52 @@ def test_site_sharded_tiles_equal_single_handle(capi, world, periodic, interval,
             h.close()
 
 
+def test_config3_workload_as_eight_site_ranges(capi):
+    """BASELINE config 3's own workload -- N = 1e5 particles on L = 2e5 sites (config 2's system) split 8 ways by site range --
+    on ONE device: eight site-sharded handles with the library's halo interval (aps_propose / aps_halo_copy / aps_commit driven
+    from here) against the single handle, 60 steps: merged state, {W, S, occupancy} on the own sites, ownership (the single
+    handle equals the oracle at this size: test_full_baseline_size_*, test_resident_loop_equals_one_launch_per_step_at_config2).
+    The same workload through aps_step with the peer-store transport, one PROCESS per range:
+    tests/test_gpu_multiprocess.py::test_config3_workload_across_processes_by_peer_stores."""
+    L, N, world, nsteps = 200000, 100000, 8, 60
+    par = params(L=L, K=1, sigma=0.005, rate_diffusion=0.02, rate_active=5.0, beta=0.7)
+    rng = np.random.default_rng(3)
+    pos = rng.choice(L, size=N, replace=False).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=N)
+    dt, seed = 0.0125, 99
+    ranks = [make_handle(capi, par, N, dt=dt, seed=seed, rank=r, world=world, method="tiles") for r in range(world)]
+    single = make_handle(capi, par, N, dt=dt, seed=seed, method="tiles")
+    try:
+        k = ranks[0].halo_info()[0]
+        assert k >= 2, k                                     # 64 tiles per rank, reach 11: the library keeps a ghost zone
+        for h in ranks + [single]:
+            h.set_state(pos, spin)
+        for _ in range(nsteps):
+            for h in ranks:
+                h.propose()
+            if ranks[0].halo_info()[2]:
+                for r, h in enumerate(ranks):
+                    for q in (r - 1, r + 1):
+                        if 0 <= q < world:
+                            h.halo_from(ranks[q])
+            for h in ranks:
+                h.commit()
+        single.step(nsteps)
+        p, s, b, a, seen = _merged_state(ranks, N)
+        assert np.array_equal(seen, np.ones(N, int))
+        for x, y in zip((p, s, b, a), single.get_state()):
+            assert np.array_equal(x, y)
+        assert not np.array_equal(p, pos)
+        Ws, Ss, occs = single.get_lattice()
+        for h in ranks:
+            lo, hi = h.owned_sites()
+            W, S, occ = h.get_lattice()
+            assert np.array_equal(W[lo:hi], Ws[lo:hi]) and np.array_equal(S[lo:hi], Ss[lo:hi]) and np.array_equal(occ[lo:hi], occs[lo:hi])
+    finally:
+        for h in ranks + [single]:
+            h.close()
+
+
 def _oracle_window_field(table, pos, spin, L, a, b):
     """W, S on the sites [a, b) by the oracle's lattice formula (histogram -> stencil with the reflected images, the
     arithmetic of oracle/sync_oracle.c:field_at) restricted to a window.  Every weight sits on the grid 2^-q, so these

@@ -226,7 +226,9 @@ def test_exclusion_driver_call_sequence():
         local_kernel_sigma=0.002, minus_anchor=True, periodic=False, immobilize_when_anchored=True,
         anchor_radius=0.003, anchor_positions=None, site_capacity=3, crowding_suppresses_rates=False,
         k_on=0, k_off=0, k_exit=0, rng=np.random.default_rng(2024))
+    assert ps.mode == "gillespie_gpu"          # an unchanged driver gets the reference's exact event loop (ref :511-516), on the GPU
     out = ps.run(T=20, obs_dt=0.5, record_fft=True, record_var=True)
+    assert ps.n_events > 10000
     mean_v_eff = ps.plot_individuals(out, show_k_max=5, cmap_name='viridis', xlim=1)
     assert ps.L == 1000 and ps.dx == 1e-3 and ps.K == 3
     assert len(out["times_obs"]) == 40 and out["total_list"].shape == (40, 1000)
@@ -327,8 +329,7 @@ def test_custom_flip_rate_fn_reproduces_reference_trajectories(golden):
         tol = 1e-7 if c["ctor"].get("periodic") else 2e-11
         assert np.max(np.abs(out["m_local_list"] - g[pre + "m_local_list"])) <= tol
         assert np.array_equal(np.array(out["exit_times"], dtype=float), g[pre + "exit_times"])
-        with pytest.raises(NotImplementedError, match="gillespie"):
-            ParticleSystem(flip_rate_fn=fn, **c["ctor"])
+        assert ParticleSystem(flip_rate_fn=fn, **c["ctor"]).mode == "gillespie"      # a callable and no mode: the exact host-draw loop
 
 
 def test_structure_observables_on_device_equal_host_function():

@@ -210,3 +210,65 @@ def test_a_call_that_gives_up_is_repeated_the_ordinary_way(capi):
         same_state(h, orc)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("case", [
+    # config 2's geometry (two workgroups on every CU) at reduced size, two ensembles, an EVEN call: ensemble 1 and the far tiles of
+    # ensemble 0 finish all n steps and write their final state and the step word before the call is given up
+    dict(tag="k1_two_ensembles_even", L=70000, K=1, sigma=0.002, betas=[0.7, 1.9], frac=0.4, n=12, stall="200:4"),
+    dict(tag="k2_odd", L=3000, K=2, sigma=0.01, betas=[1.1], frac=0.6, n=9, stall="3:2"),
+    dict(tag="k1_tile_never_starts", L=3000, K=1, sigma=0.01, betas=[0.7], frac=0.5, n=10, stall="5:0"),
+], ids=lambda c: c["tag"])
+def test_a_wait_that_runs_out_mid_loop(capi, case):
+    """APS_LOOP_TEST_STALL=<tile>:<iteration>: that tile leaves at the top of that iteration without its record and without
+    raising the give-up word -- a workgroup that is not resident.  Its neighbours' waits run out (2 ms here) while other tiles
+    are iterations ahead or already done; everyone leaves, aps_step repeats the call with one launch per step from the intact
+    inputs: same bits as the oracle after the call and after 20 further steps (the device step words included: the random
+    numbers of the repeated steps are those of the right step indices)."""
+    par0 = params(L=case["L"], K=case["K"], sigma=case["sigma"])
+    betas = case["betas"]
+    rng = np.random.default_rng(21)
+    N = max(1, int(case["frac"] * par0.L * par0.K))
+    states = [random_state(rng, par0.L, N, par0.K) for _ in betas]
+    dt, seed = 0.04, 31
+    orcs = []
+    for e, b in enumerate(betas):
+        orc = so.SyncOracle(params(L=case["L"], K=case["K"], sigma=case["sigma"], beta=b), dt=dt, seed=seed, ensemble=e)
+        orc.set_state(*states[e])
+        orcs.append(orc)
+    h = make_handle(capi, par0, N, dt=dt, seed=seed, method="tiles", beta=betas)
+    os.environ["APS_LOOP_MIN"] = "3"
+    try:
+        for e, (p, s) in enumerate(states):
+            h.set_state(p, s, ensemble=e)
+
+        def same(tag):
+            for e, orc in enumerate(orcs):
+                got = h.get_state(ensemble=e)
+                assert np.array_equal(got[0], orc.pos) and np.array_equal(got[1], orc.spin) and np.array_equal(got[2], orc.bound), (tag, e)
+                check_lattice(h, orc, ensemble=e)
+
+        h.step(5)                                            # the loop works on this handle
+        for orc in orcs:
+            orc.run(5)
+        assert h.loop_info()[:2] == (5, 1), h.loop_info()
+        same("before")
+        os.environ["APS_LOOP_TEST_STALL"], os.environ["APS_LOOP_TIMEOUT_MS"] = case["stall"], "2"
+        try:
+            h.step(case["n"])
+        finally:
+            del os.environ["APS_LOOP_TEST_STALL"], os.environ["APS_LOOP_TIMEOUT_MS"]
+        for orc in orcs:
+            orc.run(case["n"])
+        taken, state, why = h.loop_info()
+        assert (taken, state) == (0, -1) and "ran out" in why, (taken, state, why)
+        assert h.time()[1] == 5 + case["n"]
+        same("after the repeated call")
+        h.step(20)
+        for orc in orcs:
+            orc.run(20)
+        assert h.loop_info()[:2] == (0, -1)
+        same("20 steps later")
+    finally:
+        del os.environ["APS_LOOP_MIN"]
+        h.close()
