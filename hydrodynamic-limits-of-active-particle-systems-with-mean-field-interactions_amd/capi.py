@@ -129,8 +129,13 @@ def load():
         "aps_ipc_export": (C.c_int, [vp, vp]),
         "aps_ipc_connect": (C.c_int, [vp, vp, vp]),
         "aps_exchange_kind": (C.c_int, [vp]),
+        "aps_set_flip_table": (C.c_int, [vp, vp, i32]),
+        "aps_tiles_info": (C.c_int, [vp, P(i32), P(i32), P(i32), P(i32)]),
     }
+    lenient = os.environ.get("APS_LIB_LENIENT") == "1"     # tuning tools that load an older build of the library for A/B timing
     for name, (res, args) in protos.items():
+        if lenient and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     lib._aps_protos = protos
@@ -301,6 +306,22 @@ class Handle:
         the halo itself -- packed blocks stored straight into the neighbour's memory, one arrival word per block."""
         keep = [None if b is None else (C.c_uint8 * 256).from_buffer_copy(b) for b in (left_blob, right_blob)]
         self._ck(self.lib.aps_ipc_connect(self._h, *[None if k is None else C.cast(k, C.c_void_p) for k in keep]))
+
+    def set_flip_table(self, table):
+        """A caller's flip_rate_fn tabulated over m in [-1, 1]: table[2][n + 1], row 0 sigma = +1, row 1 sigma = -1 (None: back to
+        the Curie-Weiss rate); every rate evaluation of this handle interpolates it linearly (aps_set_flip_table)."""
+        if table is None:
+            self._ck(self.lib.aps_set_flip_table(self._h, None, 0))
+            return
+        tab = np.ascontiguousarray(table, dtype=np.float64)
+        assert tab.ndim == 2 and tab.shape[0] == 2 and tab.shape[1] >= 2
+        self._ck(self.lib.aps_set_flip_table(self._h, _ptr(tab), tab.shape[1] - 1))
+
+    def tiles_info(self):
+        """dict(frame_sites, owned_sites, n_tiles, table_in_lds) of a tiles handle (aps_tiles_info)."""
+        v = [C.c_int32() for _ in range(4)]
+        self._ck(self.lib.aps_tiles_info(self._h, *[C.byref(x) for x in v]))
+        return dict(frame_sites=v[0].value, owned_sites=v[1].value, n_tiles=v[2].value, table_in_lds=bool(v[3].value))
 
     def exchange_kind(self):
         """How `step` moves the halo of a sharded handle: "ipc-peer", "rccl" or "none" (the caller moves it)."""

@@ -61,6 +61,10 @@ struct Model {               // by-value kernel argument: everything the rate co
     double rate_diffusion, rate_active, k_on, k_off, k_exit, dt;
     uint32_t seed_lo, seed_hi;
     int ens_base;
+    // a caller's flip_rate_fn (ref :59-62, applied at :261-262), tabulated by the host: flip_tab[(spin > 0 ? 0 : flip_n + 1) + i]
+    // = fn(spin, -1 + 2 i / flip_n), i = 0 .. flip_n; NULL: the Curie-Weiss rate exp(-beta spin m) of ref :60
+    int flip_n;
+    const double *flip_tab;
 };
 
 struct Channels { double diff, act, flip, bind, unbind, leave, left, right, total; };
@@ -71,7 +75,16 @@ __device__ inline Channels channels(const Model &M, bool anchored_site, int p, i
                                     double beta, int occ_self, int occ_left, int occ_right) {
     const int L = M.L, K = M.K;
     const bool plus = spin > 0;
-    double flip = aps_exp(-beta * (double)spin * mloc);
+    double flip;
+    if (M.flip_tab) {                                        // linear interpolation of the caller's tabulated rate in m (m is clipped to [-1, 1])
+        const double u = (mloc + 1.0) * (0.5 * (double)M.flip_n);
+        int i = (int)u;
+        i = i < 0 ? 0 : (i >= M.flip_n ? M.flip_n - 1 : i);
+        const double f = u - (double)i;
+        const double *tb = M.flip_tab + (plus ? 0 : M.flip_n + 1);
+        const double a = tb[i], b = tb[i + 1];
+        flip = a + f * (b - a);
+    } else flip = aps_exp(-beta * (double)spin * mloc);
     if (M.suppress_flip && bound) flip = 0.0;
     // target sites: forward = right neighbour for +, own site for -; walls clip, torus wraps
     const bool wall_l = !M.periodic && p == 0, wall_r = !M.periodic && p == L - 1;

@@ -1399,11 +1399,13 @@ __global__ __launch_bounds__(256) void structure_dft(const uint32_t *__restrict_
 
 // coarse-grained site histograms: particles of either spin per bin of `bin_sites` consecutive sites (the PDE grid of the
 // hydrodynamic-limit comparison, BASELINE config 5); exact integers
-__global__ __launch_bounds__(256) void bin_counts(const uint32_t *__restrict__ src, int Npad, int bin_sites, unsigned long long *plus, unsigned long long *minus) {
+__global__ __launch_bounds__(256) void bin_counts(const uint32_t *__restrict__ src, int Npad, int bin_sites, unsigned long long *plus, unsigned long long *minus,
+                                                  int site_lo, int site_hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Npad) return;
     const uint32_t w = src[i];
     if (w & (DEAD_BIT | AWAY_BIT)) return;
+    if ((int)(w & POS_MASK) < site_lo || (int)(w & POS_MASK) >= site_hi) return;       // a site-sharded handle counts the particles on its own sites
     atomicAdd(((w & SPIN_BIT) ? plus : minus) + (w & POS_MASK) / (uint32_t)bin_sites, 1ull);
 }
 
@@ -1484,6 +1486,7 @@ struct aps_handle {
     std::string loop_why;                                      // why the loop is not used
     // fp32 mode: the tile kernel's field is int32 in units of 2^-q; d_wsb then serves as the double2 view the hooks read
     bool f32 = false, ws_view_stale = false;
+    double *d_flip_tab = nullptr;              // aps_set_flip_table
     int *d_table_i = nullptr;
     int2 *d_wsi[2] = {nullptr, nullptr};
     // site-range sharding of the tiles formulation: this rank steps tiles [ts_lo, ts_hi) = sites [own_lo, own_hi)
@@ -2639,6 +2642,7 @@ void aps_destroy(aps_handle *h) {
     for (int b = 0; b < 2; ++b)
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
+    if (h->d_flip_tab) (void)hipFree(h->d_flip_tab);
     for (void *q : h->ipc_opened) if (q) (void)hipIpcCloseMemHandle(q);
     if (h->ipc_land) (void)hipFree(h->ipc_land);
     if (h->d_ipc_done) (void)hipFree(h->d_ipc_done);
@@ -3167,7 +3171,8 @@ int aps_observe_bins(aps_handle *h, int32_t e, int32_t nbins, int64_t *plus, int
     HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&d), (size_t)2 * nbins * 8));
     auto done = [&](int code) { (void)hipFree(d); return code; };
     if (hipMemsetAsync(d, 0, (size_t)2 * nbins * 8, h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_bins: memset failed"));
-    hipLaunchKernelGGL(bin_counts, dim3((unsigned)(h->Npad / 256)), dim3(256), 0, h->stream, h->d_src + (size_t)e * h->Npad, (int)h->Npad, bin_sites, d, d + nbins);
+    hipLaunchKernelGGL(bin_counts, dim3((unsigned)(h->Npad / 256)), dim3(256), 0, h->stream, h->d_src + (size_t)e * h->Npad, (int)h->Npad, bin_sites, d, d + nbins,
+                       is_tiles(h) && h->world > 1 ? h->own_lo : 0, is_tiles(h) && h->world > 1 ? h->own_hi : h->p.L);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(plus, d, (size_t)nbins * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipMemcpyAsync(minus, d + nbins, (size_t)nbins * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) return done(fail(h, APS_ERR_HIP, "aps_observe_bins: kernel or copy failed"));
@@ -3400,6 +3405,34 @@ int aps_ipc_connect(aps_handle *h, const uint8_t *left_blob, const uint8_t *righ
         for (int par = 0; par < 2; ++par) h->ipc_peer_off[side][par] = (size_t)b[side].land_off[par][side];
     }
     h->ipc_on = true;
+    return APS_OK;
+}
+
+int aps_set_flip_table(aps_handle *h, const double *table, int32_t n) {
+    if (!h) return APS_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->graphs_built_f[0] || h->graphs_built_f[1]) drop_graphs(h);      // captured kernels hold the rate parameters by value
+    if (h->d_flip_tab) { (void)hipFree(h->d_flip_tab); h->d_flip_tab = nullptr; }
+    h->model.flip_tab = nullptr; h->model.flip_n = 0;
+    if (table) {
+        if (n < 1 || n > (1 << 24)) return fail(h, APS_ERR_ARG, "aps_set_flip_table: n must be in [1, 2^24]");
+        for (int64_t i = 0; i < 2 * ((int64_t)n + 1); ++i)
+            if (!(table[i] >= 0.0) || !std::isfinite(table[i])) return fail(h, APS_ERR_ARG, "aps_set_flip_table: rates must be finite and >= 0");
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_flip_tab), (size_t)2 * ((size_t)n + 1) * sizeof(double)));
+        HIP_TRY(h, hipMemcpy(h->d_flip_tab, table, (size_t)2 * ((size_t)n + 1) * sizeof(double), hipMemcpyHostToDevice));
+        h->model.flip_tab = h->d_flip_tab; h->model.flip_n = n;
+    }
+    if (h->d_model) HIP_TRY(h, hipMemcpy(h->d_model, &h->model, sizeof(Model), hipMemcpyHostToDevice));
+    return APS_OK;
+}
+
+int aps_tiles_info(aps_handle *h, int32_t *frame_sites, int32_t *owned_sites, int32_t *n_tiles, int32_t *table_in_lds) {
+    if (!h) return APS_ERR_ARG;
+    if (!is_tiles(h)) return fail(h, APS_ERR_STATE, "aps_tiles_info: not a tiles handle");
+    if (frame_sites) *frame_sites = 64 * h->ts_RS;
+    if (owned_sites) *owned_sites = h->ts_own;
+    if (n_tiles) *n_tiles = h->ts_ntile;
+    if (table_in_lds) *table_in_lds = h->ts_table_in_lds ? 1 : 0;
     return APS_OK;
 }
 

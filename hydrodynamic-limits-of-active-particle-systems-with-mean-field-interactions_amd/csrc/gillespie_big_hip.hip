@@ -504,6 +504,13 @@ int gil_run_large(const gil_params *p, int32_t n0, const int32_t *pos0, const in
     if (bound0) UPB(bound0, bound0, (size_t)std::max(n0, 1));
     if (p->anchor_mask) UPB(anchor, p->anchor_mask, (size_t)L);
     if (uniforms) UPB(uniforms, uniforms, (size_t)p->max_events * 4);
+    M.flip_n = 0; M.flip_tab = nullptr;
+    if (p->flip_table) {                                       // a caller's flip_rate_fn, tabulated (aps_set_flip_table's layout)
+        if (p->flip_n < 1 || p->flip_n > (1 << 24)) return bad("flip_n must be in [1, 2^24]");
+        M.flip_tab = d.upload(p->flip_table, (size_t)2 * ((size_t)p->flip_n + 1));
+        if (!M.flip_tab) { g_big_err = "gil_run_large: device upload failed (flip_table)"; return GIL_ERR_HIP; }
+        M.flip_n = p->flip_n;
+    }
     ALB(pos, int, (size_t)N); ALB(occ, int, (size_t)L); ALB(occp, int, (size_t)L); ALB(slot, int, (size_t)L * p->K); ALB(work, int, (size_t)N);
     ALB(flg, uint8_t, (size_t)N); ALB(rate, double, (size_t)N); ALB(bsum, double, (size_t)a.nblk); ALB(W, double, (size_t)L); ALB(S, double, (size_t)L);
     if (pos_obs) ALB(pos_obs, int32_t, SO);

@@ -457,6 +457,13 @@ int gil_run_batch(const gil_params *p, const int32_t *n0, const int32_t *pos0, c
     if (p->anchor_mask) UPL(anchor, p->anchor_mask, (size_t)L);
     if (p->front_lo) UPL(front_lo, p->front_lo, (size_t)L);
     if (p->block_table) UPL(block_table, p->block_table, (size_t)(p->K + 1) * (p->K + 1));
+    M.flip_n = 0; M.flip_tab = nullptr;
+    if (p->flip_table) {                                       // a caller's flip_rate_fn, tabulated (aps_set_flip_table's layout)
+        if (p->flip_n < 1 || p->flip_n > (1 << 24)) return bad("flip_n must be in [1, 2^24]");
+        M.flip_tab = d.upload(p->flip_table, (size_t)2 * ((size_t)p->flip_n + 1));
+        if (!M.flip_tab) { g_gil_err = "gil_run_batch: device upload failed (flip_table)"; return GIL_ERR_HIP; }
+        M.flip_n = p->flip_n;
+    }
     if (uniforms) UPL(uniforms, uniforms, (size_t)S * p->max_events * 4);
     OUTB(pos_obs, pos_obs, SO * ncap); OUTB(sigma_obs, sigma_obs, SO * ncap); OUTB(flags_obs, flags_obs, SO * ncap);
     if (scalars_obs) { a.scalars = d.alloc<long long>(SO * GIL_NSCALARS); if (!a.scalars) { g_gil_err = "gil_run_batch: device allocation failed (scalars)"; return GIL_ERR_HIP; } }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
     __syncthreads();                                           // F of "iteration -1"
 
 #ifdef APS_LOOP_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t0;
 #define TLSTAMP(k) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t1_ - st_t0; st_t0 = t1_; }
 #else
@@ -383,8 +383,30 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
                     const unsigned long long mv = __ballot(valid);
                     more = active && ((mv >> (sub * 16 + 15)) & 1ull) && (page + 1) * NSLOT < la.drec;
                 }
-                // by class; near a reflecting wall the image of a deposit is the same deposit at the mirrored site (small boxes: image list)
                 const uint32_t en_ = en + TS_BIAS;
+                if (!wall) {                                   // (uniform) no image of any deposit reaches this frame: three classes, nothing else
+                    const int cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2;
+                    const bool cP = valid && cw != 0 && cw == cs, cM = valid && cw != 0 && cw != cs, cF = valid && cw == 0;
+                    const unsigned long long kP = __ballot(cP), kM = __ballot(cM), kF = __ballot(cF);
+                    const unsigned long long add = (unsigned long long)__popcll(kP) | ((unsigned long long)__popcll(kM) << 16) | ((unsigned long long)__popcll(kF) << 32);
+                    if (add) {
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(shcnt, add);
+                        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+                        // (one uniform test per round whether any list runs over: only then the per-entry checks)
+                        const bool room = (int)(blo & 0xFFFFu) + __popcll(kP) <= CAP && (int)(blo >> 16) + __popcll(kM) <= CAP && (int)(bhi & 0xFFFFu) + __popcll(kF) <= CAP;
+#define TL_POOL(MASK, COND, WORD, CLS, BASE) { \
+                        const int i_ = (int)(BASE) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((MASK) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(MASK), 0u)); \
+                        if ((COND) && (room || i_ < CAP)) shl[(CLS) * CAP + i_] = (WORD); \
+                        if (!room) { const unsigned long long o_ = __ballot((COND) && i_ >= CAP); if (o_) sweep_now(o_, (WORD), (CLS)); } }
+                        TL_POOL(kP, cP, en_, 0, blo & 0xFFFFu) TL_POOL(kM, cM, en_, 1, blo >> 16) TL_POOL(kF, cF, en_, 2, bhi & 0xFFFFu)
+#undef TL_POOL
+                    }
+                    active = more;
+                    if (!__ballot(active)) break;
+                    continue;
+                }
+                // by class; near a reflecting wall the image of a deposit is the same deposit at the mirrored site (small boxes: image list)
                 const int dp = (int)(en & POS_MASK), cw = (int)((en_ >> 27) & 3u) - 1, cs = (int)(en_ >> 29) - 2;
                 const bool img_l = valid && wall && (x0c + dp + 1 <= Rt), img_r = valid && wall && (2 * L - 1 - x1c - dp <= Rt);
                 const bool cP = cw != 0 && cw == cs, cM = cw != 0 && cw != cs, cF = cw == 0;
@@ -415,8 +437,9 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
             }
         }
         if (gave_up && lane == 0) misc[TL_ABORT] = 1;
-        TLSTAMP(1)
+        TLSTAMP(8)
         __syncthreads();                                       // S: the lists are complete
+        TLSTAMP(9)
         if (misc[TL_ABORT]) return;                            // uniform: some wait ran out (here or in another workgroup)
         {
             const unsigned long long tot = *shcnt;
@@ -461,13 +484,14 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
                 }
             }
         }
+        TLSTAMP(10)
 #pragma unroll
         for (int r = 0; r < RS; ++r) {                         // W = P + M, S = P - M + F (+ the image deposits), exact on the weight grid
             const W dw = (accP[r] + accM[r]) + accWi[r], ds = ((accP[r] - accM[r]) + accF[r]) + accSi[r];
             if (dw != 0) tl_lds_add(&fieldW[r * 64 + lane], dw);
             if (ds != 0) tl_lds_add(&fieldS[r * 64 + lane], ds);
         }
-        TLSTAMP(1)
+        TLSTAMP(11)
         __syncthreads();                                       // B: field, cells, occupancy and particle list of the frame complete
         TLSTAMP(7)
         // ------------------------------------------------------------ 2  proposals, a lane per particle
@@ -653,10 +677,11 @@ __global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_lo
         __syncthreads();                                       // F: list and occupancy of the owned sites complete
     }
 #ifdef APS_LOOP_STAMPS
-    if (t == 0 && tile < 4096 && e == 0) {
-        unsigned long long *o = a.rare->stamps + (size_t)tile * 8;
-        for (int k = 0; k < 6; ++k) o[k] = st_acc[k];
-        o[6] = __builtin_amdgcn_s_memtime() - st_begin; o[7] = st_acc[7];
+    if (lane == 0 && tile < 512 && e == 0) {                   // [tile][wave][16]
+        unsigned long long *o = a.rare->stamps + ((size_t)tile * FU_WAVES + wave) * 16;
+        for (int k = 0; k < 12; ++k) o[k] = st_acc[k];
+        o[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        o[1] = st_acc[8] + st_acc[9] + st_acc[10] + st_acc[11];
     }
 #endif
 }

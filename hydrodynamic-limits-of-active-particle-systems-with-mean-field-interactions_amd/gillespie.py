@@ -23,10 +23,11 @@ class GilParams(C.Structure):
     _fields_ = [("L", C.c_int32), ("K", C.c_int32), ("periodic", C.c_int32), ("minus_anchor", C.c_int32),
                 ("immobilize", C.c_int32), ("suppress_flip", C.c_int32), ("crowding", C.c_int32), ("n_systems", C.c_int32),
                 ("n_cap", C.c_int32), ("n_obs", C.c_int32), ("device", C.c_int32), ("x_wall", C.c_int32),
-                ("ref_obs", C.c_int32), ("reserved", C.c_int32), ("sigma_grid", C.c_double), ("rate_diffusion", C.c_double),
+                ("ref_obs", C.c_int32), ("flip_n", C.c_int32), ("sigma_grid", C.c_double), ("rate_diffusion", C.c_double),
                 ("rate_active", C.c_double), ("k_on", C.c_double), ("k_off", C.c_double), ("k_exit", C.c_double),
                 ("T", C.c_double), ("seed", C.c_uint64), ("max_events", C.c_int64), ("beta", C.c_void_p),
-                ("anchor_mask", C.c_void_p), ("times_obs", C.c_void_p), ("front_lo", C.c_void_p), ("block_table", C.c_void_p)]
+                ("anchor_mask", C.c_void_p), ("times_obs", C.c_void_p), ("front_lo", C.c_void_p), ("block_table", C.c_void_p),
+                ("flip_table", C.c_void_p)]
 
 
 def _lib():
@@ -49,7 +50,7 @@ def _p(a):
 def run_raw(*, L, K, periodic, sigma_grid, rate_diffusion, rate_active, betas, states, times_obs, T, seed=0,
             minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False, k_on=0.0, k_off=0.0, k_exit=0.0,
             anchor_mask=None, uniforms=None, max_events=None, want_states=True, x_wall=0, ref_obs=-1, front_lo=None,
-            block_table=None, device=0):
+            block_table=None, device=0, flip_table=None):
     """`states` = list of (pos, sigma[, bound]) per system.  Returns a dict of arrays with a leading system axis."""
     lib = _lib()
     S = len(states)
@@ -72,7 +73,8 @@ def run_raw(*, L, K, periodic, sigma_grid, rate_diffusion, rate_active, betas, s
     mask = None if anchor_mask is None or not np.any(anchor_mask) else np.ascontiguousarray(anchor_mask, dtype=np.uint8)
     flo = None if front_lo is None else np.ascontiguousarray(front_lo, dtype=np.int32)
     btab = None if block_table is None else np.ascontiguousarray(block_table, dtype=np.uint8)
-    par = GilParams(L=L, K=K, periodic=int(bool(periodic)), minus_anchor=int(bool(minus_anchor)), immobilize=int(bool(immobilize)),
+    ftab = None if flip_table is None else np.ascontiguousarray(flip_table, dtype=np.float64)      # [2][n + 1] (aps_set_flip_table)
+    par = GilParams(flip_n=0 if ftab is None else ftab.shape[1] - 1, flip_table=None if ftab is None else _p(ftab).value, L=L, K=K, periodic=int(bool(periodic)), minus_anchor=int(bool(minus_anchor)), immobilize=int(bool(immobilize)),
                     suppress_flip=int(bool(suppress_flip)), crowding=int(bool(crowding)), n_systems=S, n_cap=ncap, n_obs=M,
                     device=device, x_wall=int(x_wall), ref_obs=int(ref_obs), sigma_grid=float(sigma_grid),
                     rate_diffusion=float(rate_diffusion), rate_active=float(rate_active), k_on=float(k_on), k_off=float(k_off),
@@ -121,7 +123,8 @@ def run_batched_exact(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var
                                 rate_active=first.rate_active, beta=float(ps.beta), state=st, times_obs=times_obs, T=T, seed=seed + s,
                                 minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
                                 suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,
-                                k_off=first.k_off, k_exit=first.k_exit, anchor_mask=first.is_anchor_site, device=first.device)
+                                k_off=first.k_off, k_exit=first.k_exit, anchor_mask=first.is_anchor_site, device=first.device,
+                                flip_table=first.flip_table())
             parts.append(one)
         ncap = max(p["pos"].shape[1] for p in parts)
 
@@ -142,7 +145,8 @@ def run_batched_exact(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var
                 rate_active=first.rate_active, betas=[float(ps.beta) for ps in systems], states=inits, times_obs=times_obs, T=T,
                 seed=seed, minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
                 suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,
-                k_off=first.k_off, k_exit=first.k_exit, anchor_mask=first.is_anchor_site, uniforms=uniforms, device=first.device)
+                k_off=first.k_off, k_exit=first.k_exit, anchor_mask=first.is_anchor_site, uniforms=uniforms, device=first.device,
+                flip_table=first.flip_table())
     outs = []
     for s, ps in enumerate(systems):
         n0 = int(r["n0"][s])
@@ -203,7 +207,7 @@ def run_batched_exact_statistics(systems, T=10.0, obs_dt=0.01):
                 seed=seed, minus_anchor=first.minus_anchor, immobilize=first.immobilize_when_anchored,
                 suppress_flip=first.suppress_flip_when_bound, crowding=first.crowding_suppresses_rates, k_on=first.k_on,
                 k_off=first.k_off, k_exit=0.0, anchor_mask=first.is_anchor_site, want_states=False, x_wall=acc0.x_wall,
-                ref_obs=acc0.start, front_lo=front_lo, block_table=tables[0], device=first.device)
+                ref_obs=acc0.start, front_lo=front_lo, block_table=tables[0], device=first.device, flip_table=first.flip_table())
     rows = []
     for s, ps in enumerate(systems):
         if int(r["n_recorded"][s]) < len(times_obs):
@@ -220,7 +224,7 @@ def run_batched_exact_statistics(systems, T=10.0, obs_dt=0.01):
 
 def run_large_raw(*, L, K, periodic, sigma_grid, rate_diffusion, rate_active, beta, state, times_obs, T, seed=0,
                   minus_anchor=True, immobilize=True, suppress_flip=True, crowding=False, k_on=0.0, k_off=0.0, k_exit=0.0,
-                  anchor_mask=None, uniforms=None, max_events=None, want_states=True, device=0):
+                  anchor_mask=None, uniforms=None, max_events=None, want_states=True, device=0, flip_table=None):
     """One large system (gil_run_large): state = (pos, sigma[, bound]).  Returns a dict like run_raw's, without a system axis."""
     lib = _lib()
     pos0 = np.ascontiguousarray(state[0], dtype=np.int32)
@@ -236,7 +240,9 @@ def run_large_raw(*, L, K, periodic, sigma_grid, rate_diffusion, rate_active, be
         max_events = 2 ** 40
     betas = np.array([float(beta)])
     mask = None if anchor_mask is None or not np.any(anchor_mask) else np.ascontiguousarray(anchor_mask, dtype=np.uint8)
-    par = GilParams(L=L, K=K, periodic=int(bool(periodic)), minus_anchor=int(bool(minus_anchor)), immobilize=int(bool(immobilize)),
+    ftab = None if flip_table is None else np.ascontiguousarray(flip_table, dtype=np.float64)
+    par = GilParams(flip_n=0 if ftab is None else ftab.shape[1] - 1, flip_table=None if ftab is None else _p(ftab).value,
+                    L=L, K=K, periodic=int(bool(periodic)), minus_anchor=int(bool(minus_anchor)), immobilize=int(bool(immobilize)),
                     suppress_flip=int(bool(suppress_flip)), crowding=int(bool(crowding)), n_systems=1, n_cap=max(n0, 1), n_obs=M,
                     device=device, x_wall=0, ref_obs=-1, sigma_grid=float(sigma_grid), rate_diffusion=float(rate_diffusion),
                     rate_active=float(rate_active), k_on=float(k_on), k_off=float(k_off), k_exit=float(k_exit), T=float(T),

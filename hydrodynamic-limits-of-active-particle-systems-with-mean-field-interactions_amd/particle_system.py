@@ -26,6 +26,34 @@ import numpy as np
 from . import capi
 
 
+FLIP_TABLE_N = 1 << 16
+
+
+def tabulate_flip_rate(fn, n=FLIP_TABLE_N):
+    """A caller's flip_rate_fn(sigma, m) (reference :59-62: applied elementwise to the arrays sigma and m_field[pos], :261-262) on
+    the uniform grid m_i = -1 + 2 i / n for sigma = +1 and -1: the [2][n + 1] table the device modes interpolate linearly.
+    Error of the interpolated rate <= max |d2 rate / dm2| (2 / n)^2 / 8 (1.2e-10 x the second derivative at n = 2^16; a jump of
+    the callable is smeared over one cell of width 3e-5).  Raises ValueError when the callable is not elementwise, or returns
+    something that is not a finite rate >= 0 -- such a callable runs with mode="gillespie" (host draws) only."""
+    m = np.linspace(-1.0, 1.0, n + 1)
+    rows = []
+    rng = np.random.default_rng(12345)
+    pick = rng.choice(n + 1, size=257, replace=False)
+    for sg in (1, -1):
+        sig = np.full(n + 1, sg, dtype=np.int8)
+        try:
+            r = np.asarray(fn(sig, m), dtype=float)
+            part = np.asarray(fn(sig[pick], m[pick]), dtype=float)
+        except Exception as exc:                                # noqa: BLE001
+            raise ValueError(f"flip_rate_fn cannot be tabulated for the device modes ({exc!r}); use mode='gillespie'") from exc
+        if r.shape != m.shape or part.shape != (257,) or not np.array_equal(r[pick], part):
+            raise ValueError("flip_rate_fn is not elementwise in (sigma, m): it cannot be tabulated for the device modes; use mode='gillespie'")
+        if not np.all(np.isfinite(r)) or np.any(r < 0):
+            raise ValueError("flip_rate_fn must return finite rates >= 0 on m in [-1, 1]")
+        rows.append(r)
+    return np.ascontiguousarray(np.stack(rows))
+
+
 class ParticleSystem:
     def __init__(self, L, xlim, rate_diffusion, rate_active, beta, flip_rate_fn=None, init="fixed",
                  N=1000, rho0_plus=None, rho0_minus=None, rng=None, scale_rates=True,
@@ -93,11 +121,11 @@ class ParticleSystem:
             raise ValueError("mode must be 'sync' (fixed-dt stepper), 'gillespie' (one exact event per iteration, drawn "
                              "from rng on the host) or 'gillespie_gpu' (the exact event loop resident on the GPU)")
         self.mode = mode
+        self._flip_table = None
         if flip_rate_fn is not None and mode != "gillespie":
-            raise NotImplementedError(
-                f"flip_rate_fn is a host callable: it is supported by mode='gillespie' (the reference's exact event loop, "
-                f"rates of the other channels from the GPU); mode={mode!r} evaluates the Curie-Weiss rate exp(-beta*sigma*m) "
-                f"on the device and cannot call back into Python")
+            # the device modes cannot call back into Python: the callable is tabulated here over m in [-1, 1] for sigma = +-1 and
+            # the kernels interpolate the table linearly (aps_set_flip_table); mode="gillespie" applies the callable itself
+            self._flip_table = tabulate_flip_rate(flip_rate_fn)
         if method not in capi.METHODS:
             raise ValueError("method must be 'auto', 'tiles' (one kernel per step over site tiles), 'lattice' (incremental lattice "
                              "field, three kernels) or 'pairs' (all-pairs kernel)")
@@ -145,7 +173,8 @@ class ParticleSystem:
     # ------------------------------------------------------------------ stepper plumbing
     def default_dt(self):
         """0.1 / (upper bound of one particle's total rate): max_i r_i * dt <= 0.1."""
-        rmax = (2.0 * self.rate_diffusion + self.rate_active + math.exp(abs(self.beta))
+        flip_max = math.exp(abs(self.beta)) if self._flip_table is None else float(self._flip_table.max())
+        rmax = (2.0 * self.rate_diffusion + self.rate_active + flip_max
                 + max(self.k_on, self.k_off) + self.k_exit)
         return 0.1 / rmax
 
@@ -161,6 +190,17 @@ class ParticleSystem:
             immobilize=self.immobilize_when_anchored, suppress_flip=self.suppress_flip_when_bound,
             crowding=self.crowding_suppresses_rates, k_on=self.k_on, k_off=self.k_off, k_exit=self.k_exit,
             anchor_mask=self.is_anchor_site, device=self.device, sort_by_site=self.sort_by_site, method=self.method, fp32=self.fp32)
+
+    def _stepper_handle(self, *args, **kw):
+        """_make_handle plus the tabulated flip rate, for the fixed-dt stepper"""
+        h = self._make_handle(*args, **kw)
+        if self._flip_table is not None:
+            h.set_flip_table(self._flip_table)
+        return h
+
+    def flip_table(self):
+        """[2][n + 1] table of a custom flip_rate_fn for the device modes (None: Curie-Weiss rate, or mode="gillespie")."""
+        return self._flip_table
 
     def _utility_handle(self):
         if self._util is None:
@@ -353,6 +393,8 @@ def run_batched(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var=False
                 raise ValueError(f"run_batched: systems differ in {k}")
         if not np.array_equal(ps.is_anchor_site, first.is_anchor_site):
             raise ValueError("run_batched: systems differ in anchor sites")
+        if (ps.flip_table() is None) != (first.flip_table() is None) or (ps.flip_table() is not None and not np.array_equal(ps.flip_table(), first.flip_table())):
+            raise ValueError("run_batched: systems differ in flip_rate_fn")
     L, dx = first.L, first.dx
     inits = [ps.init_particles() for ps in systems]
     # the reference only requires choice / poisson / exponential / random of an rng object (ref :75-78)
@@ -363,7 +405,7 @@ def run_batched(systems, T=10.0, obs_dt=0.01, record_fft=False, record_var=False
         ps.dt, ps.seed_used = first.dt, seed
     dt = first.dt
     cap = max(1, max(len(p) for p, _ in inits))
-    h = first._make_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
+    h = first._stepper_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
     E = len(systems)
     try:
         for e, (pos0, sigma0) in enumerate(inits):
@@ -437,7 +479,7 @@ def run_batched_statistics(systems, T=10.0, obs_dt=0.01):
         ps.dt, ps.seed_used = first.dt, seed
     dt = first.dt
     cap = max(1, max(len(p) for p, _ in inits))
-    h = first._make_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
+    h = first._stepper_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
     times_obs = np.arange(0.0, T, obs_dt)
     accs = [observables.DeviceObservables(times_obs, first.L, first.dx, first.K) for _ in systems]
     try:
@@ -498,7 +540,7 @@ def run_batched_structure(systems, T=10.0, obs_dt=0.01, start_fraction=0.5, k_ma
         ps.dt, ps.seed_used = first.dt, seed
     dt = first.dt
     cap = max(1, max(len(p) for p, _ in inits))
-    h = first._make_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
+    h = first._stepper_handle(cap, seed, betas=[float(ps.beta) for ps in systems], ensemble_base=first.ensemble)
     times_obs = np.arange(0.0, T, obs_dt)
     kk = first.L if k_max is None else min(int(k_max), first.L)
     accs = [observables.DeviceStructure(len(times_obs), first.L, first.dx, start_fraction, kk) for _ in systems]

@@ -244,6 +244,17 @@ int aps_step_timed(aps_handle *h, int64_t nsteps, double *kernel_ms, int64_t *la
  * kernel by kernel. */
 int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps);
 
+/* A caller's flip_rate_fn (ref :59-62, applied elementwise to (sigma, m_field[pos]) at :261-262) on the device: the host
+ * evaluates the callable on a uniform grid of m in [-1, 1] and hands over table[2][n + 1] -- row 0: sigma = +1, row 1: sigma = -1,
+ * column i: m = -1 + 2 i / n -- which every rate evaluation of this handle then interpolates linearly instead of evaluating
+ * exp(-beta sigma m) (error <= max |d2 rate / dm2| (2 / n)^2 / 8; exact for rates linear in m between grid points).  NULL
+ * returns to the Curie-Weiss rate.  Rates must be finite and >= 0. */
+int aps_set_flip_table(aps_handle *h, const double *table, int32_t n);
+
+/* Geometry of a TILES handle: sites per workgroup frame (64 RS), sites a tile owns, number of tiles, whether the weight table
+ * sits in LDS (else: windows of it, tile_step's windowed sweep). */
+int aps_tiles_info(aps_handle *h, int32_t *frame_sites, int32_t *owned_sites, int32_t *n_tiles, int32_t *table_in_lds);
+
 /* Resident loop (TILES, one rank, weight table in LDS, local field, no exits, the whole grid of tiles resident on the device
  * at once -- BASELINE config 2): aps_step then runs its steps inside ONE launch; every tile keeps its state on chip and
  * exchanges only deposit lists and boundary cells with its neighbours between two steps.  Same bits as one launch per step

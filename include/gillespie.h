@@ -35,7 +35,7 @@ typedef struct gil_params {
     int32_t device;
     int32_t x_wall;             /* first site counted as "at the right wall" in the scalar sums */
     int32_t ref_obs;            /* observation index whose positions are the origin of the displacement sums (-1: none) */
-    int32_t reserved;
+    int32_t flip_n;             /* intervals of flip_table (0: none) */
     double sigma_grid, rate_diffusion, rate_active, k_on, k_off, k_exit;
     double T;                   /* the loop ends when t > T or after the last observation time (ref :511-538) */
     uint64_t seed;              /* Philox key; counter = (event index, system index) */
@@ -45,6 +45,8 @@ typedef struct gil_params {
     const double *times_obs;    /* [n_obs], increasing, times_obs[0] is recorded before the first event */
     const int32_t *front_lo;    /* [L] or NULL: lowest site of the front window when the right-most particle sits at site s */
     const uint8_t *block_table; /* [(K+1)*(K+1)] or NULL: does a right neighbour with (plus, minus) particles block? */
+    const double *flip_table;   /* [2][flip_n + 1] or NULL: a caller's flip_rate_fn tabulated over m in [-1, 1] (row 0: sigma = +1, row 1: -1),
+                                   interpolated linearly instead of exp(-beta sigma m) (ref :59-62, :261-262; aps_set_flip_table) */
 } gil_params;
 
 const char *gil_last_error(void);

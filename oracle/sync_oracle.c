@@ -32,7 +32,7 @@ typedef struct {
     int32_t immobilize;      /* ref :82  */
     int32_t suppress_flip;   /* ref :54  */
     int32_t crowding;        /* ref :55  */
-    int32_t reserved;
+    int32_t flip_n;          /* intervals of flip_tab (0: the Curie-Weiss rate of ref :60) */
     double rate_diffusion;   /* already scaled, ref :45-50 */
     double rate_active;
     double beta;
@@ -41,6 +41,8 @@ typedef struct {
     uint64_t seed;
     uint32_t ensemble;
     uint32_t reserved2;
+    const double *flip_tab;  /* [2][flip_n + 1] or NULL: a caller's flip_rate_fn (ref :59-62, applied at :261-262) on the grid
+                                m = -1 + 2 i / flip_n, row 0: sigma = +1, row 1: sigma = -1; interpolated linearly in m */
 } orc_params;
 
 /* ------------------------------------------------------------------ Philox4x32-10 (Random123) */
@@ -282,7 +284,16 @@ static void channels(const orc_params *P, const uint8_t *anchor, int32_t p, int 
                      const int32_t *occ, chan_t *c, double (*expfn)(double)) {
     const int32_t L = P->L, K = P->K;
     const int plus = spin > 0;
-    double flip = expfn(-P->beta * (double)spin * m);                   /* ref :60, :262 */
+    double flip;
+    if (P->flip_tab) {                                                  /* ref :59-62 with a tabulated callable, :261-262 */
+        const double u = (m + 1.0) * (0.5 * (double)P->flip_n);
+        int32_t i = (int32_t)u;
+        i = i < 0 ? 0 : (i >= P->flip_n ? P->flip_n - 1 : i);
+        const double fr = u - (double)i;
+        const double *tb = P->flip_tab + (plus ? 0 : P->flip_n + 1);
+        const double a = tb[i], b = tb[i + 1];
+        flip = a + fr * (b - a);
+    } else flip = expfn(-P->beta * (double)spin * m);                   /* ref :60, :262 */
     if (P->suppress_flip && bound) flip = 0.0;                          /* ref :266-267 */
     int32_t f = p + (plus ? 1 : 0), l = p - 1, r = p + 1;               /* ref :276-291 */
     if (P->periodic) { f %= L; l = (l + L) % L; r %= L; }

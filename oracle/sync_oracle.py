@@ -18,10 +18,10 @@ _lib = None
 class OrcParams(C.Structure):
     _fields_ = [("L", C.c_int32), ("K", C.c_int32), ("periodic", C.c_int32), ("field_mode", C.c_int32),
                 ("tlen", C.c_int32), ("minus_anchor", C.c_int32), ("immobilize", C.c_int32),
-                ("suppress_flip", C.c_int32), ("crowding", C.c_int32), ("reserved", C.c_int32),
+                ("suppress_flip", C.c_int32), ("crowding", C.c_int32), ("flip_n", C.c_int32),
                 ("rate_diffusion", C.c_double), ("rate_active", C.c_double), ("beta", C.c_double),
                 ("k_on", C.c_double), ("k_off", C.c_double), ("k_exit", C.c_double), ("dt", C.c_double),
-                ("seed", C.c_uint64), ("ensemble", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("seed", C.c_uint64), ("ensemble", C.c_uint32), ("reserved2", C.c_uint32), ("flip_tab", C.c_void_p)]
 
 
 def lib():
@@ -67,8 +67,11 @@ def build_table(sigma_grid, L, K, periodic, sum_bits=51):
 
 
 class SyncOracle:
-    def __init__(self, par: LatticeGasParams, dt: float, seed: int, ensemble: int = 0, raw_table=None, sum_bits=51):
+    def __init__(self, par: LatticeGasParams, dt: float, seed: int, ensemble: int = 0, raw_table=None, sum_bits=51, flip_table=None):
+        """flip_table: [2][n + 1] tabulation of a custom flip_rate_fn (sigma = +1 / -1 over m in [-1, 1]), interpolated linearly --
+        the product's device modes do the same (include/aps.h: aps_set_flip_table)."""
         self.par = par
+        self.flip_table = None if flip_table is None else np.ascontiguousarray(flip_table, dtype=np.float64)
         self.dt = float(dt)
         if par.sigma_kernel > 0:
             if raw_table is None:
@@ -84,7 +87,9 @@ class SyncOracle:
                            suppress_flip=int(par.suppress_flip_when_bound),
                            crowding=int(par.crowding_suppresses_rates), rate_diffusion=par.rate_diffusion,
                            rate_active=par.rate_active, beta=par.beta, k_on=par.k_on, k_off=par.k_off,
-                           k_exit=par.k_exit, dt=self.dt, seed=int(seed) & (2**64 - 1), ensemble=int(ensemble))
+                           k_exit=par.k_exit, dt=self.dt, seed=int(seed) & (2**64 - 1), ensemble=int(ensemble),
+                           flip_n=0 if self.flip_table is None else self.flip_table.shape[1] - 1,
+                           flip_tab=None if self.flip_table is None else self.flip_table.ctypes.data)
         self.anchor = np.ascontiguousarray(par.is_anchor_site, dtype=np.uint8)
         self.step_index = 0
         self.exit_log = np.zeros((0, 3))

@@ -133,4 +133,4 @@ def test_gillespie_header_symbols_exported_and_struct_layout():
             rest = decl.rsplit(None, 1)[1] if "," not in decl else decl.split(None, 1)[1]
             fields += [f.strip().lstrip("*") for f in rest.split(",")]
     assert fields == [f[0] for f in gil.GilParams._fields_]
-    assert C.sizeof(gil.GilParams) == 14 * 4 + 7 * 8 + 8 + 8 + 5 * 8
+    assert C.sizeof(gil.GilParams) == 14 * 4 + 7 * 8 + 8 + 8 + 6 * 8

@@ -105,7 +105,7 @@ def test_communicator_argument_and_ordering_errors(capi):
         assert lib.aps_comm_ranks(a._h, C.byref(n)) == capi.APS_ERR_STATE         # no communicator yet
         for h in (a, b, c, sharded):
             h.set_state(pos, spin)
-        with pytest.raises(capi.ApsError, match="communicator"):
+        with pytest.raises(capi.ApsError, match="without transport"):
             sharded.step(1)                                                       # sharded handle, no communicator, no hand-driven halo
         with pytest.raises(capi.ApsError):
             sharded.halo_from(a)                                                  # not a neighbour rank of that shape

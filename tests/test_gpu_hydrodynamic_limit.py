@@ -59,8 +59,10 @@ def test_particle_ensemble_density_matches_pde_at_beta_zero():
     assert (com1 - com0) * dx > 0.12                           # drift ~ lam / 2 * T = 0.18
 
 
-def test_config5_particles_against_pde_at_full_size():
-    """BASELINE config 5 at size: N ~ 1e6 particles on L = 2e6 sites (fixed-dt stepper, tiles formulation) against
+@pytest.mark.parametrize("fp32,world,betas", [(False, 1, ((0.7, False), (1.6, True))), (True, 1, ((0.7, False),)), (True, 8, ((0.7, False),))],
+                         ids=["f64", "i32", "i32-8-site-ranges"])
+def test_config5_particles_against_pde_at_full_size(fp32, world, betas):
+    """BASELINE config 5 at size (as worded: float32 = the 32-bit field, 8 GPUs = eight site ranges, here emulated on one device): N ~ 1e6 particles on L = 2e6 sites (fixed-dt stepper, tiles formulation) against
     IMEXPDE(bc="neumann", active_model="anchored_minus", gaussian_kernel=True, kernel_sigma=0.005) on L_pde = 1000 cells,
     both on the GPU, coarse-grained on the device (aps_observe_bins), from the same initial densities
     (tools/compare_hydrodynamic.py: parameter mapping, normalisation and the gamma convention are stated there).
@@ -71,8 +73,8 @@ def test_config5_particles_against_pde_at_full_size():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import compare_hydrodynamic as ch
-    for beta, grows in ((0.7, False), (1.6, True)):
-        res = ch.compare(L=2_000_000, L_pde=1000, T=1.0, beta=beta)
+    for beta, grows in betas:
+        res = ch.compare(L=2_000_000, L_pde=1000, T=1.0, beta=beta, fp32=fp32, world=world)
         assert 0.98e6 < res["N"] < 1.02e6 and len(res["rows"]) >= 4
         noise = res["sampling_noise_m"]                       # ~0.032
         first, last = res["rows"][0], res["rows"][-1]

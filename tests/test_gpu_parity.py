@@ -269,6 +269,26 @@ def test_error_paths(capi):
         h.close()
 
 
+_FULL_SIZE_ORACLES = {}
+
+
+def _full_size_oracles(par, pos, spin):
+    """The oracle's trajectory of the BASELINE-size system (about 2 s per step on the CPU) is the same for every formulation:
+    stepped once per session, snapshots at steps 0, 15 and 49 as oracles of their own."""
+    if not _FULL_SIZE_ORACLES:
+        orc = so.SyncOracle(par, dt=0.0125, seed=0)
+        orc.set_state(pos, spin)
+        done = 0
+        for upto in (0, 15, 49):
+            orc.run(upto - done)
+            done = upto
+            snap = so.SyncOracle(par, dt=0.0125, seed=0)
+            snap.set_state(orc.pos, orc.spin, bound=orc.bound, alive=orc.alive)
+            snap.step_index = orc.step_index
+            _FULL_SIZE_ORACLES[upto] = snap
+    return _FULL_SIZE_ORACLES
+
+
 def test_full_size_properties(capi, method):
     """BASELINE config 2 shape (N=1e5, L=2e5, K=1, sigma_g=1000): properties that need no oracle run:
     exclusion, conservation, |dx| <= 1 per step, sorted == unsorted bit for bit, a spot check of
@@ -285,8 +305,8 @@ def test_full_size_properties(capi, method):
         a.set_state(pos, spin)
         b.set_state(pos, spin)
         # S and W at full size against the oracle (lattice formulation, ~1 s on the CPU)
-        orc = so.SyncOracle(par, dt=0.0125, seed=0)
-        orc.set_state(pos, spin)
+        orcs = _full_size_oracles(par, pos, spin)
+        orc = orcs[0]
         S0, W0, occ0 = orc.pair_sums()
         S, W, occ4 = a.pair_accumulate()
         assert np.array_equal(S, S0) and np.array_equal(W, W0) and np.array_equal(occ4, occ0)
@@ -300,13 +320,13 @@ def test_full_size_properties(capi, method):
             assert aa.all() and np.bincount(pa, minlength=L).max() <= 1
             assert np.abs(pa.astype(int) - prev).max() <= 5
             prev = pa.astype(int)
-        orc.run(15)
+        orc = orcs[15]
         assert np.array_equal(pa, orc.pos) and np.array_equal(sa, orc.spin)
         check_lattice(a, orc)
         if method in ("lattice", "tiles"):      # through the graph-replay path (>= 33 steps per call), field still exact
             a.step(34)                          # (the oracle needs ~2 s per step at this size)
             b.step(34)
-            orc.run(34)
+            orc = orcs[49]
             pa, sa, _, _ = a.get_state()
             assert np.array_equal(pa, orc.pos) and np.array_equal(sa, orc.spin)
             assert np.array_equal(pa, b.get_state()[0])
@@ -902,6 +922,44 @@ def test_fp32_field_is_exact_on_its_own_grid(capi, case):
         _, _, m_fine = fine.field_sites()
         _, _, m_coarse = orc.field_sites()
         assert np.max(np.abs(m_fine - m_coarse)) < 2e-4, tag       # float32-class, far above the 2e-11 of the exact grid
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("periodic", [False, True], ids=["walls", "torus"])
+def test_fp32_windowed_sweep_dense_buckets(capi, periodic):
+    """32-bit field with a table beyond LDS even at 4 bytes per entry (52 718 entries): interior tiles sweep double-buffered
+    windows of the table with directional gathers (tile_step.hpp: ts_group_dir), tiles near a wall and every tile of a torus
+    gather from the table in global memory.  Two dense clusters (K = 3, ~300 events per tile and step: several list pages per
+    bucket, the one-by-one path for buckets with more than 16 deposits) and a thin background, so the oracle's O(N taps) step
+    stays affordable.  State after every block and {W, S, occupancy} on ALL sites against the oracle with the same coarse
+    table, bit for bit.  (FP32_CASES' own "table_beyond_lds" fits LDS at 4 bytes per entry; config 5's windows are otherwise
+    only met at N = 1e6, where the oracle can check windows of sites but no trajectory.)"""
+    par = params(L=90000, K=3, sigma=0.15, rate_diffusion=3.0, periodic=periodic)
+    rng = np.random.default_rng(1)
+    L = par.L
+    sites = np.concatenate([rng.integers(20000, 21500, 2500), rng.integers(60000, 61000, 2000), rng.integers(0, L, 1000), np.arange(L - 40, L), np.arange(0, 30)])
+    u, c = np.unique(sites, return_counts=True)
+    pos = rng.permutation(np.concatenate([np.repeat(x, min(k, 3)) for x, k in zip(u, c)])).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=len(pos))
+    N = len(pos)
+    orc = so.SyncOracle(par, dt=0.05, seed=5, sum_bits=29)
+    orc.set_state(pos, spin)
+    h = make_handle(capi, par, N, dt=0.05, seed=5, method="tiles", fp32=True)
+    try:
+        info = h.tiles_info()
+        assert not info["table_in_lds"], info
+        tab, q = h.table()
+        assert q == orc.q and np.array_equal(tab, orc.table)
+        h.set_state(pos, spin)
+        for block, n in enumerate((1, 6, 5)):
+            h.step(n)
+            orc.run(n)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin), block
+            if block != 1:
+                check_lattice(h, orc)
+        assert (p != pos).mean() > 0.4
     finally:
         h.close()
 

@@ -45,19 +45,57 @@ def initial_condition(L, seed):
     return pos[order], np.where(plus, 1, -1).astype(np.int8)[order]
 
 
+class _Ranks:
+    """`world` site-range handles of ONE system on one device (BASELINE config 5 says 8 GPUs: the same sharding, emulated; the halo
+    travels by aps_halo_copy, what the peer-store / RCCL transports move between GPUs), or the single handle for world = 1."""
+
+    def __init__(self, capi, world, **kw):
+        self.world = world
+        self.hs = [capi.Handle(rank=r, world=world, method="tiles" if world > 1 else "auto", **kw) for r in range(world)]
+
+    def set_state(self, pos, spin):
+        for h in self.hs:
+            h.set_state(pos, spin)
+
+    def step(self, n):
+        if self.world == 1:
+            return self.hs[0].step(n)
+        for _ in range(int(n)):
+            for h in self.hs:
+                h.propose()
+            if self.hs[0].halo_info()[2]:
+                for r, h in enumerate(self.hs):
+                    for q in (r - 1, r + 1):
+                        if 0 <= q < self.world:
+                            h.halo_from(self.hs[q])
+            for h in self.hs:
+                h.commit()
+
+    def observe_bins(self, nbins):
+        """plus / minus counts per bin, added over the ranks (each counts the particles on its own sites)"""
+        parts = [h.observe_bins(nbins) for h in self.hs]
+        return sum(p[0] for p in parts), sum(p[1] for p in parts)
+
+    def close(self):
+        for h in self.hs:
+            h.close()
+
+
 def compare(L=2_000_000, L_pde=1000, T=1.0, beta=0.7, sigma=0.005, rate_active=5.0, rate_diffusion=0.02, dt=0.0125,
-            dt_pde=5e-4, seed=0, n_obs=4, device=0):
+            dt_pde=5e-4, seed=0, n_obs=4, device=0, fp32=False, world=1):
+    """fp32: the 32-bit field of aps_params.fp32 (BASELINE config 5 says float32); world: site-range shards (it says 8 GPUs)."""
     capi = importlib.import_module(PKG + ".capi")
     pde = importlib.import_module(PKG + ".pde")
     assert L % L_pde == 0
     dx, dx_pde = 1.0 / L, 1.0 / L_pde
     pos, spin = initial_condition(L, seed)
     N = len(pos)
-    h = capi.Handle(L=L, K=1, periodic=False, sigma_grid=sigma / dx, rate_diffusion=rate_diffusion, rate_active=rate_active,
-                    beta=[beta], dt=dt, seed=seed, n_particles=N, device=device)
+    h = _Ranks(capi, world, L=L, K=1, periodic=False, sigma_grid=sigma / dx, rate_diffusion=rate_diffusion, rate_active=rate_active,
+               beta=[beta], dt=dt, seed=seed, n_particles=N, device=device, fp32=fp32)
     try:
         h.set_state(pos, spin)
         cp0, cm0 = h.observe_bins(L_pde)
+        assert int(cp0.sum() + cm0.sum()) == N
         # ---- PDE from the particles' coarse-grained initial densities
         s = pde.IMEXPDE(L=L_pde, xlim=1.0, T=T + 0.5 * dt_pde, dt=dt_pde, gamma=rate_diffusion * dx * dx, lam=rate_active * dx, beta=beta,
                         bc="neumann", active_model="anchored_minus", gaussian_kernel=True, kernel_sigma=sigma,
@@ -89,7 +127,8 @@ def compare(L=2_000_000, L_pde=1000, T=1.0, beta=0.7, sigma=0.005, rate_active=5
     finally:
         h.close()
     per_cell = N / L_pde
-    return dict(N=N, L=L, L_pde=L_pde, T=T, beta=beta, dt=dt, dt_pde=dt_pde, method="tiles", particles_per_cell=per_cell,
+    return dict(N=N, L=L, L_pde=L_pde, T=T, beta=beta, dt=dt, dt_pde=dt_pde, method="tiles", field="int32 (fp32 mode)" if fp32 else "binary64",
+                site_range_shards=world, particles_per_cell=per_cell,
                 sampling_noise_m=float(1.0 / np.sqrt(per_cell)), gamma_convention="gamma = rate_diffusion * dx^2 (lattice walk: D = r dx^2)",
                 lam=rate_active * dx, gamma=rate_diffusion * dx * dx, caveat="the PDE has no exclusion term; transport is negligible on the PDE grid at this L",
                 wall_s_particles=t_part, wall_s_pde=t_pde, rows=rows)
@@ -102,8 +141,10 @@ if __name__ == "__main__":
     ap.add_argument("--T", type=float, default=1.0)
     ap.add_argument("--beta", type=float, default=0.7)
     ap.add_argument("--json", default="")
+    ap.add_argument("--fp32", action="store_true", help="the 32-bit field (BASELINE config 5: float32)")
+    ap.add_argument("--world", type=int, default=1, help="site-range shards emulated on one device (BASELINE config 5: 8)")
     a = ap.parse_args()
-    res = compare(L=a.L, L_pde=a.L_pde, T=a.T, beta=a.beta)
+    res = compare(L=a.L, L_pde=a.L_pde, T=a.T, beta=a.beta, fp32=a.fp32, world=a.world)
     print(json.dumps(res, indent=1))
     if a.json:
         with open(a.json, "w") as fh:

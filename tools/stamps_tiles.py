@@ -10,7 +10,10 @@ extra = sys.argv[1:]
 if extra and not extra[0].startswith("-"):
     workload, extra = extra[0], extra[1:]
 lib = f"/tmp/libaps_stamps_tiles_{'_'.join(x.strip('-D') for x in extra)}.so"
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DAPS_STAMPS",
+if os.environ.get("APS_LIB"):                      # a stamps build made beforehand (tools/build_variant.sh ... -DAPS_STAMPS)
+    lib = os.environ["APS_LIB"]
+else:
+  subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DAPS_STAMPS",
                 *extra, "-I", os.path.join(ROOT, "include"), "-o", lib, os.path.join(ROOT, PKG, "csrc", "aps_hip.hip")], check=True)
 capi = importlib.import_module(PKG + ".capi")
 capi.LIB_PATH = lib
