@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libaps_hip.so")
+LIB_PATH = os.environ.get("APS_LIB") or os.path.join(HERE, "libaps_hip.so")     # APS_LIB: a tuning build (tools/build_variant.sh)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "aps.h")
 
 APS_OK, APS_ERR_ARG, APS_ERR_HIP, APS_ERR_STATE, APS_ERR_NODEVICE = 0, -1, -2, -3, -4
@@ -130,6 +130,7 @@ def load():
         "aps_ipc_connect": (C.c_int, [vp, vp, vp]),
         "aps_exchange_kind": (C.c_int, [vp]),
         "aps_set_flip_table": (C.c_int, [vp, vp, i32]),
+        "aps_ntt_info": (C.c_int, [vp, P(i32), P(i32), P(dbl), P(i64)]),
         "aps_tiles_info": (C.c_int, [vp, P(i32), P(i32), P(i32), P(i32)]),
     }
     lenient = os.environ.get("APS_LIB_LENIENT") == "1"     # tuning tools that load an older build of the library for A/B timing
@@ -316,6 +317,12 @@ class Handle:
         tab = np.ascontiguousarray(table, dtype=np.float64)
         assert tab.ndim == 2 and tab.shape[0] == 2 and tab.shape[1] >= 2
         self._ck(self.lib.aps_set_flip_table(self._h, _ptr(tab), tab.shape[1] - 1))
+
+    def ntt_info(self):
+        """dict(on, log2_m, prof_ms, prof_launches): does this handle update the field by the exact convolution (aps_ntt_info)"""
+        on, m, ms, n = C.c_int32(), C.c_int32(), C.c_double(), C.c_int64()
+        self._ck(self.lib.aps_ntt_info(self._h, C.byref(on), C.byref(m), C.byref(ms), C.byref(n)))
+        return dict(on=bool(on.value), log2_m=m.value, prof_ms=ms.value, prof_launches=n.value)
 
     def tiles_info(self):
         """dict(frame_sites, owned_sites, n_tiles, table_in_lds) of a tiles handle (aps_tiles_info)."""

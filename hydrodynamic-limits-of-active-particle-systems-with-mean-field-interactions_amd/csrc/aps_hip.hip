@@ -1184,6 +1184,7 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
 
 #include "tile_step.hpp"
 #include "tile_loop.hpp"
+#include "ntt_conv.hpp"
 
 // fp32 mode: the field as the tile kernel keeps it (int32, units of 2^-q) <-> the binary64 view of the other kernels; exact both ways
 __global__ __launch_bounds__(256) void ws_to_int(const double2 *__restrict__ in, int2 *__restrict__ out, size_t n, double up) {
@@ -1487,6 +1488,12 @@ struct aps_handle {
     // fp32 mode: the tile kernel's field is int32 in units of 2^-q; d_wsb then serves as the double2 view the hooks read
     bool f32 = false, ws_view_stale = false;
     double *d_flip_tab = nullptr;              // aps_set_flip_table
+    // the field update as an exact number-theoretic convolution (ntt_conv.hpp): 32-bit field, table beyond LDS, one rank, walls
+    bool ntt_on = false;
+    NttPlan ntt{};
+    uint32_t *d_ntt_sig = nullptr, *d_ntt_tab = nullptr;       // [E][2][M] residues; all the tables in one allocation
+    int *d_ntt_csig = nullptr;                                 // [E][2][M] deposit coefficients of the step (index = site + Rt), cleared by the transform
+    double prof_ntt_ms = 0.0; int64_t prof_ntt_n = 0;          // last profiling run: the convolution's launches
     int *d_table_i = nullptr;
     int2 *d_wsi[2] = {nullptr, nullptr};
     // site-range sharding of the tiles formulation: this rank steps tiles [ts_lo, ts_hi) = sites [own_lo, own_hi)
@@ -1785,7 +1792,7 @@ int launch_field(aps_handle *h, int e, const uint32_t *sp8, const int4 *tinfo, i
     return APS_OK;
 }
 
-enum { KIND_PAIR = 0, KIND_PROPOSE, KIND_CLAIM, KIND_APPLY, KIND_PLAN, KIND_PROPOSE_LATTICE, KIND_FIELD_UPDATE, KIND_TILE_STEP, KIND_END, KIND_N = KIND_END };
+enum { KIND_PAIR = 0, KIND_PROPOSE, KIND_CLAIM, KIND_APPLY, KIND_PLAN, KIND_PROPOSE_LATTICE, KIND_FIELD_UPDATE, KIND_TILE_STEP, KIND_NTT, KIND_END, KIND_N = KIND_END };
 
 // profiling runs only.  Dispatch mode: hands the next APS_K launch a start/stop event pair of its own.  Bracket mode: an
 // event in front of the launch that follows (KIND_END closes the last one of a step).
@@ -1975,6 +1982,7 @@ TileArgs tile_args(aps_handle *h, bool field_only) {
     TileArgs a{};
     const int par = (int)(h->step & 1), out = field_only ? par : par ^ 1;
     a.L = h->p.L; a.K = h->p.K; a.tlen = h->tlen; a.own = h->ts_own; a.ntile = h->ts_ntile; a.dcap = h->ts_dcap; a.par = par;
+    a.dense = h->ntt_on ? h->d_ntt_csig : nullptr; a.dense_rt = h->ntt.Rt; a.dense_m = h->ntt.m;
     a.tile_lo = h->ts_lo; a.field_only = field_only ? 1 : 0; a.field_mode = h->model.field_mode; a.ens_base = h->model.ens_base; a.E = h->E;
     a.seed_lo = h->model.seed_lo; a.seed_hi = h->model.seed_hi;
     a.model = h->d_model; a.rare = h->d_rare;
@@ -2024,6 +2032,86 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
     return APS_OK;
 }
 
+// ---- the step's deposits -> W, S of every site by ONE exact convolution (ntt_conv.hpp): five launches behind the tile kernel
+int launch_ntt_conv(aps_handle *h) {
+    const int out = (int)((h->step & 1) ^ 1);                   // the buffer the tile kernel of this step wrote
+    const NttPlan &pl = h->ntt;
+    const dim3 grid((unsigned)(((size_t)1 << pl.m) / NTT_TILE), 1u, (unsigned)h->E), block(NTT_THREADS);
+    int rc;
+    const bool timed = h->profiling && h->prof_dispatch;
+#define NTT_STRIDED(AXIS, INV, A_, CSIG, WS, FLAG) do { if ((rc = prof_mark(h, KIND_NTT))) return rc; \
+        ntt_launch_strided<AXIS, INV>(A_, grid, block, h->stream, h->k_start, h->k_stop, timed, pl, h->d_ntt_sig, CSIG, WS, FLAG); } while (0)
+    if (pl.a2 > 0) {
+        NTT_STRIDED(2, false, pl.a2, h->d_ntt_csig, (int2 *)nullptr, 1);
+        NTT_STRIDED(1, false, pl.a1, (int *)nullptr, (int2 *)nullptr, 0);
+    } else NTT_STRIDED(1, false, pl.a1, h->d_ntt_csig, (int2 *)nullptr, 1);
+    if ((rc = prof_mark(h, KIND_NTT))) return rc;
+    APS_K(h, (ntt_contig<false>), grid, block, 0, pl, h->d_ntt_sig);
+    if (pl.a2 > 0) {
+        NTT_STRIDED(1, true, pl.a1, (int *)nullptr, (int2 *)nullptr, 0);
+        NTT_STRIDED(2, true, pl.a2, (int *)nullptr, h->d_wsi[out], 1);
+    } else NTT_STRIDED(1, true, pl.a1, (int *)nullptr, h->d_wsi[out], 1);
+#undef NTT_STRIDED
+    HIP_TRY(h, hipGetLastError());
+    h->field_pending = false;                                   // nothing is left in deposit lists: ws[out] is the field of the new cells
+    return APS_OK;
+}
+
+// eligibility and tables of the convolution; called from aps_create once the geometry and the integer table exist
+int ntt_setup(aps_handle *h) {
+    h->ntt_on = false;
+    const char *env = std::getenv("APS_NTT");
+    if (env && env[0] == '0') return APS_OK;
+    const bool forced = env && env[0] == '1';
+    if (!is_tiles(h) || !h->f32 || !h->model.field_mode || h->p.periodic || h->world != 1) return APS_OK;
+    if (h->ts_table_in_lds && !forced) return APS_OK;           // the in-LDS sweep (and the resident loop) is faster for short tables
+    const int Rt = h->tlen - 1, L = h->p.L;
+    if (!(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;   // one wall image per deposit at most (tile_step's mirror_ok)
+    int m = 14;
+    while (((int64_t)1 << m) < (int64_t)L + 2 * Rt) ++m;
+    if (m > 21) return APS_OK;
+    // exactness: |dW|, |dS| <= 2 K sum_d w(d) must stay below P / 2
+    double wsum = 0.0;
+    for (int t = 0; t < h->tlen; ++t) wsum += std::ldexp(h->table[(size_t)t], h->q) * (t ? 2.0 : 1.0);
+    if (2.0 * h->p.K * wsum >= 0.5 * (double)NTT_P) return APS_OK;
+    NttPlan &pl = h->ntt;
+    pl.m = m; ntt_split(m, pl.a0, pl.a1, pl.a2); pl.L = L; pl.Rt = Rt;
+    NttTables T;
+    ntt_build_tables(m, T);
+    const size_t M = (size_t)1 << m;
+    const size_t o_wr = 0, o_t1 = o_wr + T.wr.size(), o_hi = o_t1 + T.t1.size(), o_lo = o_hi + T.t2hi.size(), o_what = o_lo + T.t2lo.size(), total = o_what + M;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_ntt_tab, total)) || (rc = dev_alloc(h, &h->d_ntt_sig, (size_t)h->E * 2 * M)) || (rc = dev_alloc(h, &h->d_ntt_csig, (size_t)h->E * 2 * M))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_wr, T.wr.data(), T.wr.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_t1, T.t1.data(), T.t1.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_hi, T.t2hi.data(), T.t2hi.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_lo, T.t2lo.data(), T.t2lo.size() * 4, hipMemcpyHostToDevice, h->stream));
+    pl.wr = h->d_ntt_tab + o_wr; pl.t1 = h->d_ntt_tab + o_t1; pl.t2hi = h->d_ntt_tab + o_hi; pl.t2lo = h->d_ntt_tab + o_lo; pl.what = h->d_ntt_tab + o_what;
+    // spectrum of the table: w(|d|) at index d mod M, forward sweeps only, times 1 / M
+    std::vector<uint32_t> wext(2 * M, 0u);
+    for (int t = 0; t < h->tlen; ++t) {
+        const uint32_t v = (uint32_t)(int)std::ldexp(h->table[(size_t)t], h->q);
+        wext[(size_t)t] = v;
+        if (t) wext[M - (size_t)t] = v;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_sig, wext.data(), wext.size() * 4, hipMemcpyHostToDevice, h->stream));
+    const dim3 grid((unsigned)(M / NTT_TILE), 1u, 1u), block(NTT_THREADS);
+    if (pl.a2 > 0) ntt_launch_strided<2, false>(pl.a2, grid, block, h->stream, nullptr, nullptr, false, pl, h->d_ntt_sig, nullptr, nullptr, 0);
+    ntt_launch_strided<1, false>(pl.a1, grid, block, h->stream, nullptr, nullptr, false, pl, h->d_ntt_sig, nullptr, nullptr, 0);
+    hipLaunchKernelGGL((ntt_contig<true>), grid, block, 0, h->stream, pl, h->d_ntt_sig);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<uint32_t> spec(M);
+    HIP_TRY(h, hipMemcpyAsync(spec.data(), h->d_ntt_sig, M * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const uint32_t minv = ntt_powmod((uint32_t)(M % NTT_P), NTT_P - 2ull);
+    for (size_t i = 0; i < M; ++i) spec[i] = ntt_mulmod_u64(spec[i], minv);
+    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_what, spec.data(), M * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_ntt_sig, 0, (size_t)h->E * 2 * M * 4, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->ntt_on = true;
+    return APS_OK;
+}
+
 // ---- resident loop (tile_loop.hpp): when every tile of the grid is resident at once, aps_step runs its steps inside ONE
 // launch.  Eligible: one rank, table in LDS, a local field, no exits, the whole grid within the kernel's residency on this
 // device.  A call that gives up (a wait ran out: the workgroups were not all resident after all) leaves the inputs intact,
@@ -2050,6 +2138,7 @@ int loop_prepare(aps_handle *h) {
     auto no = [&](const char *why) { h->loop_why = why; return APS_OK; };
     if (!is_tiles(h)) return no("not the tiles formulation");
     if (h->world != 1) return no("sharded handle");
+    if (h->ntt_on) return no("field updated by the exact convolution");
     if (!h->ts_table_in_lds) return no("weight table beyond LDS");
     if (!h->model.field_mode) return no("global mean field");
     if (h->model.immobilize && h->model.k_exit > 0.0) return no("particles can leave the system");
@@ -2405,7 +2494,11 @@ int upload_cells(aps_handle *h, int e, const int32_t *pos, const int8_t *sigma, 
 }
 
 int do_propose(aps_handle *h) {
-    if (is_tiles(h)) return launch_tile_step(h);
+    if (is_tiles(h)) {
+        int rc = launch_tile_step(h);
+        if (!rc && h->ntt_on) rc = launch_ntt_conv(h);
+        return rc;
+    }
     if (h->method == APS_METHOD_LATTICE) {
         const LatticeArgs a = lattice_args(h, false, true);
         return launch_lattice_propose(h, a, a.tile_lo, a.tile_cnt);
@@ -2610,6 +2703,7 @@ int aps_create(const aps_params *p, aps_handle **out) {
                 (rc = dev_alloc(h, &h->d_wsi[0], EL)) || (rc = dev_alloc(h, &h->d_wsi[1], EL))) return die(rc);
             if (hipMemcpyAsync(h->d_table_i, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "integer table upload failed"; return die(APS_ERR_HIP); }
+            if ((rc = ntt_setup(h))) return die(rc);
         }
         if (h->world > 1 && (rc = halo_setup(h))) return die(rc);
         const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K, ts_wbytes(h)).total;
@@ -2643,6 +2737,7 @@ void aps_destroy(aps_handle *h) {
         for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
     if (h->d_flip_tab) (void)hipFree(h->d_flip_tab);
+    for (void *q : {(void *)h->d_ntt_sig, (void *)h->d_ntt_tab, (void *)h->d_ntt_csig}) if (q) (void)hipFree(q);
     for (void *q : h->ipc_opened) if (q) (void)hipIpcCloseMemHandle(q);
     if (h->ipc_land) (void)hipFree(h->ipc_land);
     if (h->d_ipc_done) (void)hipFree(h->d_ipc_done);
@@ -2957,14 +3052,14 @@ int aps_step(aps_handle *h, int64_t nsteps) {
             if (!ge && (rc = capture_run(h, (int)(h->step & 1), (int)nsteps, &ge))) return rc;
             HIP_TRY(h, hipGraphLaunch(ge, h->stream));
             h->step += nsteps; h->last_graph_steps += nsteps; s = nsteps;
-            if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true; }
+            if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = !h->ntt_on; h->ws_view_stale = true; }
         }
         for (int g = 0; g < NGRAPH; ++g)
             for (; nsteps - s >= GRAPH_SIZES[g]; s += GRAPH_SIZES[g]) {
                 HIP_TRY(h, hipGraphLaunch(h->gexec_f[h->flip][h->step & 1][g], h->stream));
                 h->step += GRAPH_SIZES[g];
                 h->last_graph_steps += GRAPH_SIZES[g];
-                if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true; }
+                if (is_tiles(h)) { h->slots_dirty = true; h->field_pending = !h->ntt_on; h->ws_view_stale = true; }
             }
     }
     for (; s < nsteps; ++s, ++h->last_single_steps)
@@ -3059,7 +3154,17 @@ int aps_step_profile(aps_handle *h, int64_t nsteps, double *ms8, int64_t *launch
     double ms[KIND_N]; int64_t cnt[KIND_N];
     int rc = run_profiled(h, nsteps, ms, cnt, nullptr);
     if (rc) return rc;
-    for (int k = 0; k < KIND_N; ++k) { ms8[k] = ms[k]; if (launches8) launches8[k] = cnt[k]; }
+    for (int k = 0; k < 8; ++k) { ms8[k] = ms[k]; if (launches8) launches8[k] = cnt[k]; }
+    h->prof_ntt_ms = ms[KIND_NTT]; h->prof_ntt_n = cnt[KIND_NTT];
+    return APS_OK;
+}
+
+int aps_ntt_info(aps_handle *h, int32_t *on, int32_t *log2_m, double *prof_ms, int64_t *prof_launches) {
+    if (!h) return APS_ERR_ARG;
+    if (on) *on = h->ntt_on ? 1 : 0;
+    if (log2_m) *log2_m = h->ntt_on ? h->ntt.m : 0;
+    if (prof_ms) *prof_ms = h->prof_ntt_ms;
+    if (prof_launches) *prof_launches = h->prof_ntt_n;
     return APS_OK;
 }
 

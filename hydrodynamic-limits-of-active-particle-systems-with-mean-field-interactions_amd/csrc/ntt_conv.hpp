@@ -1,0 +1,322 @@
+// ntt_conv.hpp -- the field update of the 32-bit field as ONE exact convolution per step (included by aps_hip.hip inside its
+// anonymous namespace).
+//
+// Hot path replaced: compute_local_m_field (PARTICLE_solver_CLASS.py:216-246), whose smoothing the reference itself evaluates by
+// FFT on a torus (:223-227) and by scipy's gaussian_filter1d between walls (:229-238).  Here the smoothed histograms W, S are
+// state (tile_step.hpp); a step changes them by  dW = cW (*) w,  dS = cS (*) w  with cW, cS the step's deposits as sparse integer
+// signals on the lattice (a hop: -1 at the old site, +1 at the new one; a flip: -+2 in cS) and w the weight table.  For a table
+// far beyond LDS (BASELINE config 5: 80 001 taps) tile_step's sweep costs deposits x taps = 1.7e9 LDS gathers per step; the
+// convolution theorem costs O(M log M) with M = 2^21 -- and a number-theoretic transform keeps it EXACT: every W, S, dW, dS is
+// an integer (units of 2^-q) of magnitude below 2^29, the prime P = 15 * 2^27 + 1 = 2 013 265 921 exceeds twice that, so the
+// residues mod P determine the integers.  Same bits as the sweep, the oracle and every other formulation.
+//
+// Reflecting walls: the deposits within the table's reach of a wall are entered a second time at their mirror site
+// (-1 - p, 2L - 1 - p), i.e. the signals live on [-Rt, L + Rt) and a plain linear convolution gives the reference's
+// mode='reflect' sums on [0, L); M >= L + 2 Rt makes the circular convolution equal to the linear one there.
+//
+// Transform: M = R2 R1 R0 (R0 = 128 along memory, R1, R2 <= 128), index i = i0 + R0 i1 + R0 R1 i2, frequency
+// k = k2 + R2 k1 + R2 R1 k0:  w^(ik) = w_R2^(i2 k2) . w^(R0 i1 k2) . w_R1^(i1 k1) . w^(i0 (k2 + R2 k1)) . w_R0^(i0 k0)
+// -- three sweeps of small transforms held in LDS (one launch each: along i2, along i1, along i0) with two twiddle
+// multiplications in between; in place, slot i_a ends up holding k_a.  The last forward sweep, the product with the table's
+// spectrum and the first inverse sweep touch the same 128 contiguous words and are one kernel: five launches per convolution,
+// both signals in every launch.  Arithmetic: residues in [0, P) as uint32 in memory and LDS, products by binary64 fma (exact:
+// the error term of a * b and the quotient estimate both come from fma; full rate on CDNA, where 32-bit integer multiplies
+// run at a quarter).
+#pragma once
+
+constexpr uint32_t NTT_P = 2013265921u;          // 15 * 2^27 + 1
+constexpr uint32_t NTT_G = 31u;                  // a primitive root of P
+constexpr int NTT_TILE = 4096;                   // words of one signal a workgroup holds in LDS
+constexpr int NTT_THREADS = 256;
+
+__host__ __device__ inline uint32_t ntt_mulmod_u64(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) % NTT_P); }
+inline uint32_t ntt_powmod(uint32_t b, unsigned long long e) {
+    uint32_t r = 1u;
+    while (e) { if (e & 1ull) r = ntt_mulmod_u64(r, b); b = ntt_mulmod_u64(b, b); e >>= 1; }
+    return r;
+}
+
+// a * b mod P for residues held as doubles (integers in [0, P)): exact
+__device__ __forceinline__ double ntt_mul(double a, double b) {
+    const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
+    const double h = a * b, l = fma(a, b, -h);           // a b = h + l exactly
+    const double q = floor(h * Pinv);
+    double r = fma(-q, Pd, h) + l;                       // exact: an integer below 2^33 in magnitude
+    r = r < 0.0 ? r + Pd : r;
+    r = r >= Pd ? r - Pd : r;
+    return r;
+}
+__device__ __forceinline__ double ntt_add(double a, double b) { const double s = a + b; return s >= (double)NTT_P ? s - (double)NTT_P : s; }
+__device__ __forceinline__ double ntt_sub(double a, double b) { const double s = a - b; return s < 0.0 ? s + (double)NTT_P : s; }
+
+struct NttPlan {
+    int m, a0, a1, a2;                     // M = 2^m = R2 R1 R0, R_x = 2^a_x (a0 = 7; a2 = 0: two sweeps only)
+    int L, Rt;                             // lattice sites, table reach; signal index = site + Rt
+    const uint32_t *wr;                    // [2][3][64]  w_R^j for the three axes (R0, R1, R2), forward / inverse
+    const uint32_t *t1;                    // [2][R1 R2]  w^(+-R0 e)            (twiddle between the i2 and the i1 sweep, e = i1 k2)
+    const uint32_t *t2hi, *t2lo;           // [2][M / 1024], [2][1024]: w^(+-e) = hi[e >> 10] lo[e & 1023]   (e = i0 (k2 + R2 k1))
+    const uint32_t *what;                  // [M] spectrum of the table in the transform's own output order, times 1 / M
+};
+
+// ---- lazy arithmetic of the register passes: values are doubles holding integers in [0, c P) with c growing by at most a
+// factor two per butterfly level (c = 1, 3, 6, 12, 24 over four levels: far below 2^53); one full reduction per pass
+__device__ __forceinline__ double ntt_mul_lazy(double a, double b) {      // a < 2^40 (any multiple range), b in [0, P): a b mod P + {0, P, 2P}
+    const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
+    const double h = a * b, l = fma(a, b, -h);
+    const double q = floor(h * Pinv);
+    return (fma(-q, Pd, h) + l) + Pd;                                     // in (0, 3 P)
+}
+__device__ __forceinline__ uint32_t ntt_reduce(double v) {                // v an integer in [0, 2^40): v mod P
+    const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
+    const double q = floor(v * Pinv);
+    double r = fma(-q, Pd, v);
+    r = r < 0.0 ? r + Pd : r;
+    r = r >= Pd ? r - Pd : r;
+    return (uint32_t)r;
+}
+
+// B butterfly levels on the 2^B values of one thread.  The values are rows  n + (t << lo_shift), t = 0 .. 2^B - 1, of a transform
+// of size 2^A whose level `s0 + s` they carry out (decimation in frequency: pair distance 2^(A - 1 - s0 - s) rows); the twiddle of
+// the pair whose upper row is i is w_R^((i mod h) << level), taken from wtab (w_R^j, j < 64, as doubles).
+template <int B>
+__device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double *__restrict__ wtab, const int n, const int lo_shift, const int s0) {
+    constexpr double CP[5] = {1.0 * NTT_P, 3.0 * NTT_P, 6.0 * NTT_P, 12.0 * NTT_P, 24.0 * NTT_P};
+#pragma unroll
+    for (int s = 0; s < B; ++s) {
+        constexpr int NV = 1 << B;
+        const int ht = NV >> (s + 1);
+#pragma unroll
+        for (int pr = 0; pr < NV / 2; ++pr) {
+            const int j = pr & (ht - 1), u = ((pr - j) << 1) + j, v = u + ht;
+            const double xa = x[u], xb = x[v];
+            x[u] = xa + xb;
+            const double d = (xa - xb) + CP[s];                            // positive: both below CP[s]
+            const int e = (n + (j << lo_shift)) << (s0 + s);               // < 64
+            x[v] = e == 0 ? d : ntt_mul_lazy(d, wtab[e]);
+        }
+    }
+}
+
+// Transform of size 2^A (natural order in, bit-reversed order out) of the NC = 2^lg_nc columns of one signal held in LDS, element
+// (row r, column c) at buf[r * ld + c]: two register passes (2^AH = 16 rows a thread, then 2^AL = 8), residues in [0, P) between.
+template <int A>
+__device__ __forceinline__ void ntt_lds_transform(uint32_t *buf, const int lg_nc, const int ld, const double *__restrict__ wtab, const int t) {
+    constexpr int AH = A < 4 ? A : 4, AL = A - AH;
+    const int NC = 1 << lg_nc;
+    for (int w = t; w < (NC << AL); w += NTT_THREADS) {                    // pass 1: rows n + (tt << AL)
+        const int c = w & (NC - 1), n = w >> lg_nc;
+        double x[1 << AH];
+#pragma unroll
+        for (int tt = 0; tt < (1 << AH); ++tt) x[tt] = (double)buf[(n + (tt << AL)) * ld + c];
+        ntt_reg_levels<AH>(x, wtab, n, AL, 0);
+#pragma unroll
+        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = ntt_reduce(x[tt]);
+    }
+    __syncthreads();
+    if constexpr (AL > 0) {
+        for (int w = t; w < (NC << AH); w += NTT_THREADS) {                // pass 2: rows (u << AL) + v
+            const int c = w & (NC - 1), u = w >> lg_nc;
+            double x[1 << AL];
+#pragma unroll
+            for (int v = 0; v < (1 << AL); ++v) x[v] = (double)buf[((u << AL) + v) * ld + c];
+            ntt_reg_levels<AL>(x, wtab, 0, 0, AH);
+#pragma unroll
+            for (int v = 0; v < (1 << AL); ++v) buf[((u << AL) + v) * ld + c] = ntt_reduce(x[v]);
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ int ntt_bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// ---- sweep along a strided axis (i2: stride R0 R1, or i1: stride R0): a workgroup takes NC consecutive words (same other digits)
+// for all R = 2^A values of the axis digit, of both signals.
+// first forward sweep (INIT): the input are the deposit signals -- int32 coefficients, cleared behind the read -- instead of
+// residues; last inverse sweep (FINAL): the result is added to {W, S} of the sites.
+// AXIS 1: forward: multiply by w^(R0 i1 k2), transform over i1; inverse: transform, multiply by w^(-R0 i1 k2).
+template <int AXIS, bool INV, int A>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uint32_t *__restrict__ data, int *__restrict__ csig, int2 *__restrict__ ws, const int init_or_final) {
+    __shared__ uint32_t buf[2][NTT_TILE + 128];
+    __shared__ double wtab[64];
+    const int t = threadIdx.x;
+    constexpr int R = 1 << A;
+    constexpr int lg_nc = 12 - A, NC = 1 << lg_nc;               // consecutive words per axis value (>= 32)
+    static_assert(NTT_TILE == 4096, "lg_nc assumes 4096 words per tile");
+    const size_t M = (size_t)1 << pl.m;
+    const size_t stride = AXIS == 2 ? ((size_t)1 << (pl.a0 + pl.a1)) : ((size_t)1 << pl.a0);
+    const size_t per_outer = stride / NC;                        // tiles per value of the digits above the axis
+    const size_t outer = blockIdx.x / per_outer, inner0 = (blockIdx.x % per_outer) * NC;
+    const size_t base = outer * stride * R + inner0;             // word index of (axis digit 0, first column)
+    uint32_t *sig0 = data + (size_t)blockIdx.z * 2 * M, *sig1 = sig0 + M;
+    int *c0 = csig ? csig + (size_t)blockIdx.z * 2 * M : nullptr, *c1 = c0 ? c0 + M : nullptr;
+    constexpr int ld = NC + 1;
+    if (t < 64) wtab[t] = (double)pl.wr[(INV ? 192 : 0) + (AXIS == 2 ? 128 : 64) + t];
+    // ---- load (row r = axis digit, column c): + twiddle of the i1 sweep going forward
+    const int k2 = (int)outer;                                   // AXIS 1: the digit above (slot i2 holds k2)
+#pragma unroll 4
+    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
+        const int c = w & (NC - 1), r = w >> lg_nc;
+        const size_t g = base + (size_t)r * stride + c;
+        uint32_t v0, v1;
+        if (!INV && init_or_final) {                             // deposit coefficients (small signed integers), cleared for the next step
+            const int x0 = c0[g], x1 = c1[g];
+            if (x0) c0[g] = 0;
+            if (x1) c1[g] = 0;
+            v0 = x0 < 0 ? (uint32_t)((int)NTT_P + x0) : (uint32_t)x0;
+            v1 = x1 < 0 ? (uint32_t)((int)NTT_P + x1) : (uint32_t)x1;
+        } else { v0 = sig0[g]; v1 = sig1[g]; }
+        if (AXIS == 1 && !INV && r && k2) {                      // w^(R0 i1 k2), i1 = r
+            const double tw = (double)pl.t1[(size_t)r * k2];
+            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+        }
+        buf[0][r * ld + c] = v0; buf[1][r * ld + c] = v1;
+    }
+    __syncthreads();
+    ntt_lds_transform<A>(buf[0], lg_nc, ld, wtab, t);
+    ntt_lds_transform<A>(buf[1], lg_nc, ld, wtab, t);
+    // ---- store, un-permuting the bit-reversed output: slot r gets the value of frequency r
+#pragma unroll 4
+    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
+        const int c = w & (NC - 1), r = w >> lg_nc;
+        const int src = ntt_bitrev(r, A);
+        uint32_t v0 = buf[0][src * ld + c], v1 = buf[1][src * ld + c];
+        const size_t g = base + (size_t)r * stride + c;
+        if (AXIS == 1 && INV && r && k2) {                       // w^(-R0 i1 k2): the result index r is i1
+            const double tw = (double)pl.t1[((size_t)1 << (pl.a1 + pl.a2)) + (size_t)r * k2];
+            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+        }
+        if (INV && init_or_final) {                              // natural order again: word g is the change of {W, S} at site g - Rt
+            const long long site = (long long)g - pl.Rt;
+            if (site >= 0 && site < pl.L && (v0 | v1)) {
+                int2 *p = ws + (size_t)blockIdx.z * pl.L + site;
+                int2 f = *p;
+                f.x += v0 > NTT_P / 2 ? (int)(v0 - NTT_P) : (int)v0;
+                f.y += v1 > NTT_P / 2 ? (int)(v1 - NTT_P) : (int)v1;
+                *p = f;
+            }
+        } else { sig0[g] = v0; sig1[g] = v1; }
+    }
+}
+
+// ---- the contiguous axis (i0, R0 = 128): forward sweep (with its twiddle w^(i0 (k2 + R2 k1))), product with the table's spectrum,
+// inverse sweep (twiddle w^(-i0 ...)): one kernel, a workgroup takes 32 rows of 128 contiguous words of both signals.
+// FWD_ONLY: stop after the forward sweep (building the table's spectrum).
+template <bool FWD_ONLY>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint32_t *__restrict__ data) {
+    __shared__ uint32_t buf[2][NTT_TILE + 128];
+    __shared__ double wtab[2][64];
+    const int t = threadIdx.x;
+    constexpr int A0 = 7, R0 = 1 << A0, lg_nr = 12 - A0, NR = 1 << lg_nr;   // rows per tile
+    const size_t M = (size_t)1 << pl.m;
+    const size_t row0 = (size_t)blockIdx.x * NR;                 // row = (i1-slot, i2-slot) = k1 + R1 k2
+    uint32_t *sig0 = data + (size_t)blockIdx.z * 2 * M, *sig1 = sig0 + M;
+    constexpr int ld = NR + 1;                                   // element (transform row i0, tile row r) at i0 * ld + r
+    const int R1m = (1 << pl.a1) - 1;
+    if (t < 128) wtab[t >> 6][t & 63] = (double)pl.wr[(t >> 6) * 192 + (t & 63)];
+    auto twiddle2 = [&](const size_t row, const int i0, const bool inv) -> double {
+        const int k1 = (int)(row & (size_t)R1m), k2 = (int)(row >> pl.a1);
+        const unsigned long long e = (unsigned long long)i0 * ((unsigned long long)k2 + ((unsigned long long)k1 << pl.a2));   // < M
+        const uint32_t hi = pl.t2hi[(inv ? (M >> 10) : 0) + (size_t)(e >> 10)], lo = pl.t2lo[(inv ? 1024 : 0) + (size_t)(e & 1023ull)];
+        return ntt_mul((double)hi, (double)lo);
+    };
+#pragma unroll 4
+    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
+        const int i0 = w & (R0 - 1), r = w >> A0;
+        const size_t g = (row0 + r) * R0 + i0;
+        uint32_t v0 = sig0[g], v1 = sig1[g];
+        if (i0 && (row0 + r)) {
+            const double tw = twiddle2(row0 + r, i0, false);
+            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+        }
+        buf[0][i0 * ld + r] = v0; buf[1][i0 * ld + r] = v1;
+    }
+    __syncthreads();
+    ntt_lds_transform<A0>(buf[0], lg_nr, ld, wtab[0], t);
+    ntt_lds_transform<A0>(buf[1], lg_nr, ld, wtab[0], t);
+    if (FWD_ONLY) {
+        for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
+            const int i0 = w & (R0 - 1), r = w >> A0;
+            const int src = ntt_bitrev(i0, A0);
+            const size_t g = (row0 + r) * R0 + i0;
+            sig0[g] = buf[0][src * ld + r]; sig1[g] = buf[1][src * ld + r];
+        }
+        return;
+    }
+    // product with the table's spectrum, un-permuting on the way (slot i0 <- frequency i0): through registers
+    uint32_t keep0[NTT_TILE / NTT_THREADS], keep1[NTT_TILE / NTT_THREADS];
+#pragma unroll
+    for (int u = 0; u < NTT_TILE / NTT_THREADS; ++u) {
+        const int w = t + u * NTT_THREADS;
+        const int i0 = w & (R0 - 1), r = w >> A0;
+        const int src = ntt_bitrev(i0, A0);
+        const double wh = (double)pl.what[(row0 + r) * R0 + i0];
+        keep0[u] = (uint32_t)ntt_mul((double)buf[0][src * ld + r], wh);
+        keep1[u] = (uint32_t)ntt_mul((double)buf[1][src * ld + r], wh);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NTT_TILE / NTT_THREADS; ++u) {
+        const int w = t + u * NTT_THREADS;
+        const int i0 = w & (R0 - 1), r = w >> A0;
+        buf[0][i0 * ld + r] = keep0[u]; buf[1][i0 * ld + r] = keep1[u];
+    }
+    __syncthreads();
+    ntt_lds_transform<A0>(buf[0], lg_nr, ld, wtab[1], t);
+    ntt_lds_transform<A0>(buf[1], lg_nr, ld, wtab[1], t);
+#pragma unroll 4
+    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
+        const int i0 = w & (R0 - 1), r = w >> A0;
+        const int src = ntt_bitrev(i0, A0);
+        uint32_t v0 = buf[0][src * ld + r], v1 = buf[1][src * ld + r];
+        if (i0 && (row0 + r)) {
+            const double tw = twiddle2(row0 + r, i0, true);
+            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+        }
+        const size_t g = (row0 + r) * R0 + i0;
+        sig0[g] = v0; sig1[g] = v1;
+    }
+}
+
+// launch of a strided sweep whose radix is only known at run time (the i2 sweep: 2^a2, a2 = 1 .. 7)
+template <int AXIS, bool INV>
+inline void ntt_launch_strided(int a, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, bool timed, const NttPlan &pl, uint32_t *data, int *csig, int2 *ws, int flag) {
+#define NTT_CASE(AA) case AA: if (timed) hipExtLaunchKernelGGL((ntt_strided<AXIS, INV, AA>), grid, block, 0, stream, e0, e1, 0, pl, data, csig, ws, flag); \
+                              else hipLaunchKernelGGL((ntt_strided<AXIS, INV, AA>), grid, block, 0, stream, pl, data, csig, ws, flag); break;
+    switch (a) { NTT_CASE(1) NTT_CASE(2) NTT_CASE(3) NTT_CASE(4) NTT_CASE(5) NTT_CASE(6) NTT_CASE(7) default: break; }
+#undef NTT_CASE
+}
+
+// ---- host side: tables of a plan (everything mod P by 64-bit integer arithmetic)
+struct NttTables { std::vector<uint32_t> wr, t1, t2hi, t2lo; };
+inline void ntt_split(int m, int &a0, int &a1, int &a2) { a0 = 7; a1 = std::min(7, m - 7); a2 = m - 7 - a1; }
+inline void ntt_build_tables(int m, NttTables &T) {
+    int a0, a1, a2;
+    ntt_split(m, a0, a1, a2);
+    const unsigned long long M = 1ull << m;
+    const uint32_t w = ntt_powmod(NTT_G, (NTT_P - 1ull) / M), wi = ntt_powmod(w, NTT_P - 2ull);
+    T.wr.assign(2 * 192, 1u);
+    for (int inv = 0; inv < 2; ++inv) {
+        const uint32_t ww = inv ? wi : w;
+        const int as[3] = {a0, a1, a2};
+        for (int ax = 0; ax < 3; ++ax) {
+            const uint32_t wR = ntt_powmod(ww, M >> as[ax]);          // w_R = w^(M / R)
+            uint32_t cur = 1u;
+            for (int j = 0; j < 64; ++j) { T.wr[(size_t)inv * 192 + ax * 64 + j] = cur; cur = ntt_mulmod_u64(cur, wR); }
+        }
+    }
+    const size_t n1 = (size_t)1 << (a1 + a2);
+    T.t1.assign(2 * n1, 1u);
+    for (int inv = 0; inv < 2; ++inv) {
+        const uint32_t step = ntt_powmod(inv ? wi : w, 1ull << a0);    // w^(R0)
+        uint32_t cur = 1u;
+        for (size_t e = 0; e < n1; ++e) { T.t1[inv * n1 + e] = cur; cur = ntt_mulmod_u64(cur, step); }
+    }
+    const size_t nhi = std::max<size_t>(M >> 10, 1);
+    T.t2hi.assign(2 * nhi, 1u); T.t2lo.assign(2 * 1024, 1u);
+    for (int inv = 0; inv < 2; ++inv) {
+        const uint32_t ww = inv ? wi : w, step = ntt_powmod(ww, 1024ull);
+        uint32_t cur = 1u;
+        for (size_t e = 0; e < nhi; ++e) { T.t2hi[inv * nhi + e] = cur; cur = ntt_mulmod_u64(cur, step); }
+        cur = 1u;
+        for (size_t e = 0; e < 1024; ++e) { T.t2lo[inv * 1024 + e] = cur; cur = ntt_mulmod_u64(cur, ww); }
+    }
+}

@@ -31,6 +31,8 @@ struct TileRare { double *exit_log; unsigned *n_exit; uint32_t *src; const uint3
 
 struct TileArgs {
     int L, K, tlen, own, ntile, dcap, par, tile_lo, field_only, field_mode, ens_base, E;
+    int dense_rt, dense_m;                             // dense != NULL: the deposits of the step go into the coefficient signals of the
+    int *dense;                                        // convolution (ntt_conv.hpp) [E][2][2^dense_m], index = site + dense_rt, instead of lists
     uint32_t seed_lo, seed_hi;                         // Philox key
     const Model *model;                                // device copy of the rate parameters (read by the proposal phase)
     const TileRare *rare;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     }
     // buckets (= tiles) whose deposits can reach the frame: one run of nbk buckets from b0 that may wrap around the torus
     int b0 = 0, nbk = 0;
-    if (a.field_mode) {
+    if (a.field_mode && !a.dense) {                            // (dense: ws_in already holds the field of the current cells)
         if (BC == 0) {
             b0 = max(0, x0c - Rt - 1) / OWN;
             nbk = min(L - 1, x1c + Rt + 1) / OWN - b0 + 1;
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     }
     TSTAMP(f_stage)
     // ---------------------------------------------------------------- 1  deposits of the previous step -> W, S of the frame
-    const bool windowed = !TAB_LDS && BC == 0 && !wall;
+    const bool windowed = !TAB_LDS && BC == 0 && !wall && !a.dense;
     const uint32_t tb = TAB_LDS ? tbase : 0u;                  // table in global memory: byte offsets from its start
     const uint32_t win_lds = tbase;
     const int WIN = ts_win_entries(RS, OWN);
@@ -750,8 +752,21 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
             }
             if (stays) { out[n_out++] = c; my_spin += (c & CELL_PLUS) ? 1 : -1; my_live += 1; }
             if (nd && a.field_mode) {
-                const int kd = atomicAdd(&misc[0], nd);
-                if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
+                if (a.dense) {                                 // coefficient signals of the convolution, wall images included
+                    int *cw_sig = a.dense + ((size_t)e << (a.dense_m + 1)), *cs_sig = cw_sig + ((size_t)1 << a.dense_m);
+                    for (int u = 0; u < nd; ++u) {
+                        const uint32_t d = u ? d1 : d0;
+                        const int ds_ = (int)(d & POS_MASK), cw = (int)((d >> 27) & 3u) - 1, cs = (int)(d >> 29) - 2;
+                        const int at = ds_ + a.dense_rt;
+                        if (cw) atomicAdd(cw_sig + at, cw);
+                        atomicAdd(cs_sig + at, cs);
+                        const int img = ds_ < a.dense_rt ? a.dense_rt - 1 - ds_ : (ds_ >= L - a.dense_rt ? 2 * L - 1 - ds_ + a.dense_rt : -1);
+                        if (img >= 0) { if (cw) atomicAdd(cw_sig + img, cw); atomicAdd(cs_sig + img, cs); }
+                    }
+                } else {
+                    const int kd = atomicAdd(&misc[0], nd);
+                    if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
+                }
             }
         }
         const int cap = cap_at(xi);

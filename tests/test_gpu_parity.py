@@ -9,6 +9,8 @@ is run in BOTH of its formulations (`method`): the all-pairs kernel, and the lat
 (whose W, S and occupancy arrays are additionally compared with the oracle's recomputation after the runs)."""
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -959,6 +961,43 @@ def test_fp32_windowed_sweep_dense_buckets(capi, periodic):
             assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin), block
             if block != 1:
                 check_lattice(h, orc)
+        assert (p != pos).mean() > 0.4
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("sigma,L", [(0.02, 90000), (0.004, 16000), (0.1, 120000)], ids=["m17", "m14_two_sweeps", "m18_beyond_lds"])
+def test_fp32_field_update_by_exact_convolution(capi, sigma, L):
+    """csrc/ntt_conv.hpp: the step's deposits -> W, S of all sites by ONE number-theoretic convolution (mod 15 * 2^27 + 1, length
+    2^m >= L + 2 reach, wall images entered as mirrored deposits) instead of the sweep -- exact integers, so state after every
+    block and {W, S, occupancy} on ALL sites must equal the oracle's (which knows nothing of transforms) bit for bit.  Forced by
+    APS_NTT=1 for tables that fit LDS (the first two cases: transforms of three and of two sweeps); the third is beyond LDS and
+    takes the convolution by itself.  Dense clusters at both walls and inside, K = 3, a thin background."""
+    par = params(L=L, K=3, sigma=sigma, rate_diffusion=3.0)
+    rng = np.random.default_rng(2)
+    sites = np.concatenate([rng.integers(L // 4, L // 4 + 1500, 2500), rng.integers(0, L, 1500), np.arange(L - 300, L), np.arange(0, 200)])
+    u, c = np.unique(sites, return_counts=True)
+    pos = rng.permutation(np.concatenate([np.repeat(x, min(k, 3)) for x, k in zip(u, c)])).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=len(pos))
+    N = len(pos)
+    orc = so.SyncOracle(par, dt=0.05, seed=7, sum_bits=29)
+    orc.set_state(pos, spin)
+    os.environ["APS_NTT"] = "1"
+    try:
+        h = make_handle(capi, par, N, dt=0.05, seed=7, method="tiles", fp32=True)
+    finally:
+        del os.environ["APS_NTT"]
+    try:
+        info = h.ntt_info()
+        assert info["on"] and (1 << info["log2_m"]) >= L + 2 * (len(h.table()[0]) - 1), info
+        h.set_state(pos, spin)
+        check_lattice(h, orc)
+        for block, n in enumerate((1, 2, 37)):               # single steps and graph replay
+            h.step(n)
+            orc.run(n)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin), block
+            check_lattice(h, orc)
         assert (p != pos).mean() > 0.4
     finally:
         h.close()
