@@ -2036,7 +2036,7 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
 int launch_ntt_conv(aps_handle *h) {
     const int out = (int)((h->step & 1) ^ 1);                   // the buffer the tile kernel of this step wrote
     const NttPlan &pl = h->ntt;
-    const dim3 grid((unsigned)(((size_t)1 << pl.m) / NTT_TILE), 1u, (unsigned)h->E), block(NTT_THREADS);
+    const dim3 grid((unsigned)(((size_t)1 << pl.m) / NTT_TILE), 2u, (unsigned)h->E), block(NTT_THREADS);   // y: the two signals
     int rc;
     const bool timed = h->profiling && h->prof_dispatch;
 #define NTT_STRIDED(AXIS, INV, A_, CSIG, WS, FLAG) do { if ((rc = prof_mark(h, KIND_NTT))) return rc; \

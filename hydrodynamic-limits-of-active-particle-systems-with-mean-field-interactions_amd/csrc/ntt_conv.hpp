@@ -36,18 +36,23 @@ inline uint32_t ntt_powmod(uint32_t b, unsigned long long e) {
     return r;
 }
 
-// a * b mod P for residues held as doubles (integers in [0, P)): exact
+// Residues travel LAZILY: integers in [0, 2 P) (2 P < 2^32, so a uint32 holds them), as uint32 in global memory and as doubles
+// in LDS and registers.  Quotients are estimated by floor(x / P - 2^-10): never above the true quotient, at most one below it
+// for every product that occurs here (operands below 2^36 and 2^32: the estimate's error is far below 2^-10), so a remainder
+// lies in [0, 2 P) without any correction step.
+constexpr double NTT_BIAS = 0.0009765625;                        // 2^-10
+// a * b mod P, lazy: a < 2^36, b < 2^32 -> [0, 2 P).  Exact: a b = h + l with l from fma; h - q P is a small integer (fma again).
 __device__ __forceinline__ double ntt_mul(double a, double b) {
     const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
-    const double h = a * b, l = fma(a, b, -h);           // a b = h + l exactly
-    const double q = floor(h * Pinv);
-    double r = fma(-q, Pd, h) + l;                       // exact: an integer below 2^33 in magnitude
-    r = r < 0.0 ? r + Pd : r;
-    r = r >= Pd ? r - Pd : r;
-    return r;
+    const double h = a * b, l = fma(a, b, -h);
+    const double q = floor(fma(h, Pinv, -NTT_BIAS));
+    return fma(-q, Pd, h) + l;
 }
-__device__ __forceinline__ double ntt_add(double a, double b) { const double s = a + b; return s >= (double)NTT_P ? s - (double)NTT_P : s; }
-__device__ __forceinline__ double ntt_sub(double a, double b) { const double s = a - b; return s < 0.0 ? s + (double)NTT_P : s; }
+__device__ __forceinline__ double ntt_red(double v) {             // v an integer in [0, 2^40) -> [0, 2 P), congruent
+    const double q = floor(fma(v, 1.0 / (double)NTT_P, -NTT_BIAS));
+    return fma(-q, (double)NTT_P, v);
+}
+__device__ __forceinline__ uint32_t ntt_canon(uint32_t v) { return v >= NTT_P ? v - NTT_P : v; }     // [0, 2 P) -> [0, P)
 
 struct NttPlan {
     int m, a0, a1, a2;                     // M = 2^m = R2 R1 R0, R_x = 2^a_x (a0 = 7; a2 = 0: two sweeps only)
@@ -58,29 +63,15 @@ struct NttPlan {
     const uint32_t *what;                  // [M] spectrum of the table in the transform's own output order, times 1 / M
 };
 
-// ---- lazy arithmetic of the register passes: values are doubles holding integers in [0, c P) with c growing by at most a
-// factor two per butterfly level (c = 1, 3, 6, 12, 24 over four levels: far below 2^53); one full reduction per pass
-__device__ __forceinline__ double ntt_mul_lazy(double a, double b) {      // a < 2^40 (any multiple range), b in [0, P): a b mod P + {0, P, 2P}
-    const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
-    const double h = a * b, l = fma(a, b, -h);
-    const double q = floor(h * Pinv);
-    return (fma(-q, Pd, h) + l) + Pd;                                     // in (0, 3 P)
-}
-__device__ __forceinline__ uint32_t ntt_reduce(double v) {                // v an integer in [0, 2^40): v mod P
-    const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
-    const double q = floor(v * Pinv);
-    double r = fma(-q, Pd, v);
-    r = r < 0.0 ? r + Pd : r;
-    r = r >= Pd ? r - Pd : r;
-    return (uint32_t)r;
-}
-
 // B butterfly levels on the 2^B values of one thread.  The values are rows  n + (t << lo_shift), t = 0 .. 2^B - 1, of a transform
 // of size 2^A whose level `s0 + s` they carry out (decimation in frequency: pair distance 2^(A - 1 - s0 - s) rows); the twiddle of
 // the pair whose upper row is i is w_R^((i mod h) << level), taken from wtab (w_R^j, j < 64, as doubles).
-template <int B>
+// N0: n is known to be zero (the second pass): the pairs with j = 0 need no product; otherwise every pair multiplies (w_R^0 = 1
+// for the rare n = j = 0: a branch per butterfly would cost more than the product)
+template <int B, bool N0>
 __device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double *__restrict__ wtab, const int n, const int lo_shift, const int s0) {
-    constexpr double CP[5] = {1.0 * NTT_P, 3.0 * NTT_P, 6.0 * NTT_P, 12.0 * NTT_P, 24.0 * NTT_P};
+    // values entering level s are below CP[s] (lazy residues below 2 P at first; a sum doubles the bound, a product is below 2 P)
+    constexpr double CP[5] = {2.0 * NTT_P, 4.0 * NTT_P, 8.0 * NTT_P, 16.0 * NTT_P, 32.0 * NTT_P};
 #pragma unroll
     for (int s = 0; s < B; ++s) {
         constexpr int NV = 1 << B;
@@ -92,25 +83,25 @@ __device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double
             x[u] = xa + xb;
             const double d = (xa - xb) + CP[s];                            // positive: both below CP[s]
             const int e = (n + (j << lo_shift)) << (s0 + s);               // < 64
-            x[v] = e == 0 ? d : ntt_mul_lazy(d, wtab[e]);
+            if (N0 && j == 0) x[v] = d; else x[v] = ntt_mul(d, wtab[e]);
         }
     }
 }
 
 // Transform of size 2^A (natural order in, bit-reversed order out) of the NC = 2^lg_nc columns of one signal held in LDS, element
-// (row r, column c) at buf[r * ld + c]: two register passes (2^AH = 16 rows a thread, then 2^AL = 8), residues in [0, P) between.
+// (row r, column c) at buf[r * ld + c] (doubles, lazy residues): two register passes (2^AH = 16 rows a thread, then 2^AL = 8).
 template <int A>
-__device__ __forceinline__ void ntt_lds_transform(uint32_t *buf, const int lg_nc, const int ld, const double *__restrict__ wtab, const int t) {
+__device__ __forceinline__ void ntt_lds_transform(double *buf, const int lg_nc, const int ld, const double *__restrict__ wtab, const int t) {
     constexpr int AH = A < 4 ? A : 4, AL = A - AH;
     const int NC = 1 << lg_nc;
     for (int w = t; w < (NC << AL); w += NTT_THREADS) {                    // pass 1: rows n + (tt << AL)
         const int c = w & (NC - 1), n = w >> lg_nc;
         double x[1 << AH];
 #pragma unroll
-        for (int tt = 0; tt < (1 << AH); ++tt) x[tt] = (double)buf[(n + (tt << AL)) * ld + c];
-        ntt_reg_levels<AH>(x, wtab, n, AL, 0);
+        for (int tt = 0; tt < (1 << AH); ++tt) x[tt] = buf[(n + (tt << AL)) * ld + c];
+        ntt_reg_levels<AH, false>(x, wtab, n, AL, 0);
 #pragma unroll
-        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = ntt_reduce(x[tt]);
+        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = ntt_red(x[tt]);
     }
     __syncthreads();
     if constexpr (AL > 0) {
@@ -118,10 +109,10 @@ __device__ __forceinline__ void ntt_lds_transform(uint32_t *buf, const int lg_nc
             const int c = w & (NC - 1), u = w >> lg_nc;
             double x[1 << AL];
 #pragma unroll
-            for (int v = 0; v < (1 << AL); ++v) x[v] = (double)buf[((u << AL) + v) * ld + c];
-            ntt_reg_levels<AL>(x, wtab, 0, 0, AH);
+            for (int v = 0; v < (1 << AL); ++v) x[v] = buf[((u << AL) + v) * ld + c];
+            ntt_reg_levels<AL, true>(x, wtab, 0, 0, AH);
 #pragma unroll
-            for (int v = 0; v < (1 << AL); ++v) buf[((u << AL) + v) * ld + c] = ntt_reduce(x[v]);
+            for (int v = 0; v < (1 << AL); ++v) buf[((u << AL) + v) * ld + c] = ntt_red(x[v]);
         }
         __syncthreads();
     }
@@ -129,15 +120,15 @@ __device__ __forceinline__ void ntt_lds_transform(uint32_t *buf, const int lg_nc
 __device__ __forceinline__ int ntt_bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
 
 // ---- sweep along a strided axis (i2: stride R0 R1, or i1: stride R0): a workgroup takes NC consecutive words (same other digits)
-// for all R = 2^A values of the axis digit, of both signals.
+// for all R = 2^A values of the axis digit, of one signal (blockIdx.y).
 // first forward sweep (INIT): the input are the deposit signals -- int32 coefficients, cleared behind the read -- instead of
 // residues; last inverse sweep (FINAL): the result is added to {W, S} of the sites.
 // AXIS 1: forward: multiply by w^(R0 i1 k2), transform over i1; inverse: transform, multiply by w^(-R0 i1 k2).
 template <int AXIS, bool INV, int A>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uint32_t *__restrict__ data, int *__restrict__ csig, int2 *__restrict__ ws, const int init_or_final) {
-    __shared__ uint32_t buf[2][NTT_TILE + 128];
+    __shared__ double buf[NTT_TILE + 128];
     __shared__ double wtab[64];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, sgl = blockIdx.y;                 // one signal (0: W, 1: S) per workgroup
     constexpr int R = 1 << A;
     constexpr int lg_nc = 12 - A, NC = 1 << lg_nc;               // consecutive words per axis value (>= 32)
     static_assert(NTT_TILE == 4096, "lg_nc assumes 4096 words per tile");
@@ -146,54 +137,65 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
     const size_t per_outer = stride / NC;                        // tiles per value of the digits above the axis
     const size_t outer = blockIdx.x / per_outer, inner0 = (blockIdx.x % per_outer) * NC;
     const size_t base = outer * stride * R + inner0;             // word index of (axis digit 0, first column)
-    uint32_t *sig0 = data + (size_t)blockIdx.z * 2 * M, *sig1 = sig0 + M;
-    int *c0 = csig ? csig + (size_t)blockIdx.z * 2 * M : nullptr, *c1 = c0 ? c0 + M : nullptr;
+    uint32_t *sig0 = data + ((size_t)blockIdx.z * 2 + sgl) * M;
+    int *c0 = csig ? csig + ((size_t)blockIdx.z * 2 + sgl) * M : nullptr;
     constexpr int ld = NC + 1;
     if (t < 64) wtab[t] = (double)pl.wr[(INV ? 192 : 0) + (AXIS == 2 ? 128 : 64) + t];
     // ---- load (row r = axis digit, column c): + twiddle of the i1 sweep going forward
     const int k2 = (int)outer;                                   // AXIS 1: the digit above (slot i2 holds k2)
-#pragma unroll 4
-    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
-        const int c = w & (NC - 1), r = w >> lg_nc;
-        const size_t g = base + (size_t)r * stride + c;
-        uint32_t v0, v1;
-        if (!INV && init_or_final) {                             // deposit coefficients (small signed integers), cleared for the next step
-            const int x0 = c0[g], x1 = c1[g];
-            if (x0) c0[g] = 0;
-            if (x1) c1[g] = 0;
-            v0 = x0 < 0 ? (uint32_t)((int)NTT_P + x0) : (uint32_t)x0;
-            v1 = x1 < 0 ? (uint32_t)((int)NTT_P + x1) : (uint32_t)x1;
-        } else { v0 = sig0[g]; v1 = sig1[g]; }
-        if (AXIS == 1 && !INV && r && k2) {                      // w^(R0 i1 k2), i1 = r
-            const double tw = (double)pl.t1[(size_t)r * k2];
-            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+    constexpr int NI = NTT_TILE / NTT_THREADS;                   // words per thread: all their loads are issued before the first is used
+    {
+        uint32_t raw[NI], twv[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+            const size_t g = base + (size_t)r * stride + c;
+            raw[u] = (!INV && init_or_final) ? (uint32_t)c0[g] : sig0[g];
+            twv[u] = (AXIS == 1 && !INV) ? pl.t1[(size_t)r * k2] : 1u;       // w^(R0 i1 k2), i1 = r
         }
-        buf[0][r * ld + c] = v0; buf[1][r * ld + c] = v1;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+            double v0;
+            if (!INV && init_or_final) {                         // deposit coefficients (small signed integers), cleared for the next step
+                const int x0 = (int)raw[u];
+                if (x0) c0[base + (size_t)r * stride + c] = 0;
+                v0 = x0 < 0 ? (double)NTT_P + (double)x0 : (double)x0;
+            } else v0 = (double)raw[u];
+            if (AXIS == 1 && !INV) v0 = ntt_mul(v0, (double)twv[u]);
+            buf[r * ld + c] = v0;
+        }
     }
     __syncthreads();
-    ntt_lds_transform<A>(buf[0], lg_nc, ld, wtab, t);
-    ntt_lds_transform<A>(buf[1], lg_nc, ld, wtab, t);
+    ntt_lds_transform<A>(buf, lg_nc, ld, wtab, t);
     // ---- store, un-permuting the bit-reversed output: slot r gets the value of frequency r
-#pragma unroll 4
-    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
-        const int c = w & (NC - 1), r = w >> lg_nc;
-        const int src = ntt_bitrev(r, A);
-        uint32_t v0 = buf[0][src * ld + c], v1 = buf[1][src * ld + c];
-        const size_t g = base + (size_t)r * stride + c;
-        if (AXIS == 1 && INV && r && k2) {                       // w^(-R0 i1 k2): the result index r is i1
-            const double tw = (double)pl.t1[((size_t)1 << (pl.a1 + pl.a2)) + (size_t)r * k2];
-            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
-        }
-        if (INV && init_or_final) {                              // natural order again: word g is the change of {W, S} at site g - Rt
-            const long long site = (long long)g - pl.Rt;
-            if (site >= 0 && site < pl.L && (v0 | v1)) {
-                int2 *p = ws + (size_t)blockIdx.z * pl.L + site;
-                int2 f = *p;
-                f.x += v0 > NTT_P / 2 ? (int)(v0 - NTT_P) : (int)v0;
-                f.y += v1 > NTT_P / 2 ? (int)(v1 - NTT_P) : (int)v1;
-                *p = f;
+    {
+        uint32_t twv[NI];
+        int old_w[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+            twv[u] = (AXIS == 1 && INV) ? pl.t1[((size_t)1 << (pl.a1 + pl.a2)) + (size_t)r * k2] : 1u;   // w^(-R0 i1 k2): the result index r is i1
+            old_w[u] = 0;
+            if (INV && init_or_final) {                          // the sites' {W, S} this thread will add to
+                const long long site = (long long)(base + (size_t)r * stride + c) - pl.Rt;
+                if (site >= 0 && site < pl.L) old_w[u] = reinterpret_cast<const int *>(ws + (size_t)blockIdx.z * pl.L + site)[sgl];
             }
-        } else { sig0[g] = v0; sig1[g] = v1; }
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+            double d0 = buf[ntt_bitrev(r, A) * ld + c];
+            const size_t g = base + (size_t)r * stride + c;
+            if (AXIS == 1 && INV) d0 = ntt_mul(d0, (double)twv[u]);
+            const uint32_t v0 = (uint32_t)d0;
+            if (INV && init_or_final) {                          // natural order again: word g is the change of W (or S) at site g - Rt
+                const long long site = (long long)g - pl.Rt;
+                const uint32_t vc = ntt_canon(v0);
+                if (site >= 0 && site < pl.L && vc)
+                    reinterpret_cast<int *>(ws + (size_t)blockIdx.z * pl.L + site)[sgl] = old_w[u] + (vc > NTT_P / 2 ? (int)(vc - NTT_P) : (int)vc);
+            } else sig0[g] = v0;
+        }
     }
 }
 
@@ -202,77 +204,84 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
 // FWD_ONLY: stop after the forward sweep (building the table's spectrum).
 template <bool FWD_ONLY>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint32_t *__restrict__ data) {
-    __shared__ uint32_t buf[2][NTT_TILE + 128];
+    __shared__ double buf[NTT_TILE + 128];
     __shared__ double wtab[2][64];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, sgl = blockIdx.y;
     constexpr int A0 = 7, R0 = 1 << A0, lg_nr = 12 - A0, NR = 1 << lg_nr;   // rows per tile
     const size_t M = (size_t)1 << pl.m;
     const size_t row0 = (size_t)blockIdx.x * NR;                 // row = (i1-slot, i2-slot) = k1 + R1 k2
-    uint32_t *sig0 = data + (size_t)blockIdx.z * 2 * M, *sig1 = sig0 + M;
+    uint32_t *sig0 = data + ((size_t)blockIdx.z * 2 + sgl) * M;
     constexpr int ld = NR + 1;                                   // element (transform row i0, tile row r) at i0 * ld + r
     const int R1m = (1 << pl.a1) - 1;
     if (t < 128) wtab[t >> 6][t & 63] = (double)pl.wr[(t >> 6) * 192 + (t & 63)];
-    auto twiddle2 = [&](const size_t row, const int i0, const bool inv) -> double {
+    constexpr int NI = NTT_TILE / NTT_THREADS;
+    auto tw2_index = [&](const size_t row, const int i0, size_t &ihi, size_t &ilo) {
         const int k1 = (int)(row & (size_t)R1m), k2 = (int)(row >> pl.a1);
         const unsigned long long e = (unsigned long long)i0 * ((unsigned long long)k2 + ((unsigned long long)k1 << pl.a2));   // < M
-        const uint32_t hi = pl.t2hi[(inv ? (M >> 10) : 0) + (size_t)(e >> 10)], lo = pl.t2lo[(inv ? 1024 : 0) + (size_t)(e & 1023ull)];
-        return ntt_mul((double)hi, (double)lo);
+        ihi = (size_t)(e >> 10); ilo = (size_t)(e & 1023ull);
     };
-#pragma unroll 4
-    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
-        const int i0 = w & (R0 - 1), r = w >> A0;
-        const size_t g = (row0 + r) * R0 + i0;
-        uint32_t v0 = sig0[g], v1 = sig1[g];
-        if (i0 && (row0 + r)) {
-            const double tw = twiddle2(row0 + r, i0, false);
-            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+    uint32_t whatv[NI];                                          // the table's spectrum at this thread's words: asked for now, used after the forward sweep
+    {
+        uint32_t raw[NI], hi[NI], lo[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
+            const size_t g = (row0 + r) * R0 + i0;
+            size_t ihi, ilo;
+            tw2_index(row0 + r, i0, ihi, ilo);
+            raw[u] = sig0[g]; hi[u] = pl.t2hi[ihi]; lo[u] = pl.t2lo[ilo];
+            whatv[u] = FWD_ONLY ? 0u : pl.what[g];
         }
-        buf[0][i0 * ld + r] = v0; buf[1][i0 * ld + r] = v1;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
+            buf[i0 * ld + r] = ntt_mul((double)raw[u], ntt_mul((double)hi[u], (double)lo[u]));
+        }
     }
     __syncthreads();
-    ntt_lds_transform<A0>(buf[0], lg_nr, ld, wtab[0], t);
-    ntt_lds_transform<A0>(buf[1], lg_nr, ld, wtab[0], t);
+    ntt_lds_transform<A0>(buf, lg_nr, ld, wtab[0], t);
     if (FWD_ONLY) {
         for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
             const int i0 = w & (R0 - 1), r = w >> A0;
             const int src = ntt_bitrev(i0, A0);
-            const size_t g = (row0 + r) * R0 + i0;
-            sig0[g] = buf[0][src * ld + r]; sig1[g] = buf[1][src * ld + r];
+            sig0[(row0 + r) * R0 + i0] = ntt_canon((uint32_t)buf[src * ld + r]);      // (the table's spectrum is kept canonical)
         }
         return;
     }
     // product with the table's spectrum, un-permuting on the way (slot i0 <- frequency i0): through registers
-    uint32_t keep0[NTT_TILE / NTT_THREADS], keep1[NTT_TILE / NTT_THREADS];
+    double keep0[NTT_TILE / NTT_THREADS];
 #pragma unroll
     for (int u = 0; u < NTT_TILE / NTT_THREADS; ++u) {
         const int w = t + u * NTT_THREADS;
         const int i0 = w & (R0 - 1), r = w >> A0;
         const int src = ntt_bitrev(i0, A0);
-        const double wh = (double)pl.what[(row0 + r) * R0 + i0];
-        keep0[u] = (uint32_t)ntt_mul((double)buf[0][src * ld + r], wh);
-        keep1[u] = (uint32_t)ntt_mul((double)buf[1][src * ld + r], wh);
+        keep0[u] = ntt_mul(buf[src * ld + r], (double)whatv[u]);
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NTT_TILE / NTT_THREADS; ++u) {
         const int w = t + u * NTT_THREADS;
         const int i0 = w & (R0 - 1), r = w >> A0;
-        buf[0][i0 * ld + r] = keep0[u]; buf[1][i0 * ld + r] = keep1[u];
+        buf[i0 * ld + r] = keep0[u];
     }
     __syncthreads();
-    ntt_lds_transform<A0>(buf[0], lg_nr, ld, wtab[1], t);
-    ntt_lds_transform<A0>(buf[1], lg_nr, ld, wtab[1], t);
-#pragma unroll 4
-    for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
-        const int i0 = w & (R0 - 1), r = w >> A0;
-        const int src = ntt_bitrev(i0, A0);
-        uint32_t v0 = buf[0][src * ld + r], v1 = buf[1][src * ld + r];
-        if (i0 && (row0 + r)) {
-            const double tw = twiddle2(row0 + r, i0, true);
-            v0 = (uint32_t)ntt_mul((double)v0, tw); v1 = (uint32_t)ntt_mul((double)v1, tw);
+    ntt_lds_transform<A0>(buf, lg_nr, ld, wtab[1], t);
+    {
+        uint32_t hi[NI], lo[NI];
+        const size_t nhi = M >> 10;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
+            size_t ihi, ilo;
+            tw2_index(row0 + r, i0, ihi, ilo);
+            hi[u] = pl.t2hi[nhi + ihi]; lo[u] = pl.t2lo[1024 + ilo];
         }
-        const size_t g = (row0 + r) * R0 + i0;
-        sig0[g] = v0; sig1[g] = v1;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
+            const double v0 = ntt_mul(buf[ntt_bitrev(i0, A0) * ld + r], ntt_mul((double)hi[u], (double)lo[u]));
+            sig0[(row0 + r) * R0 + i0] = (uint32_t)v0;
+        }
     }
 }
 

@@ -1,5 +1,5 @@
 import os, sys, time, importlib
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 capi = importlib.import_module(bench.PKG + ".capi")
 if os.environ.get("APS_LIB"):                      # an alternative build of the library (tuning experiments)
