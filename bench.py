@@ -591,11 +591,21 @@ def main():
             # the begin -> end interval rocprofv3 --kernel-trace reports.  APS_PROF_BRACKET=1 switches to events recorded
             # around the launch instead, which read ~2 us more per kernel (the event packets' own cost).
             kern = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}
+            ntt = h.ntt_info()
+            if ntt["on"] and ntt["prof_launches"]:     # the field update as an exact convolution (csrc/ntt_conv.hpp): five launches per step
+                kern["ntt_conv"] = ntt["prof_ms"] / ntt["prof_launches"] * 1e-3
             bracketed = os.environ.get("APS_PROF_BRACKET") is not None
             dep_per_step = deposits / max(n_fu, 1)
             N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
             algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32"))) for k in kern}
-            step_bytes = sum(algo.values())
+            launches_per_step = {k: 1 for k in kern}
+            if "ntt_conv" in kern:
+                # per launch: both signals of 2^m residues read and written (4 B each); per step on top: the deposit signals read
+                # by the first sweep, the table's spectrum by the middle one, {W, S} read and written by the last one
+                M_ntt = float(1 << ntt["log2_m"]) * n_ens
+                launches_per_step["ntt_conv"] = ntt["prof_launches"] / reps
+                algo["ntt_conv"] = (launches_per_step["ntt_conv"] * 16.0 * M_ntt + 8.0 * M_ntt + 4.0 * M_ntt + 16.0 * L_all) / launches_per_step["ntt_conv"]
+            step_bytes = sum(algo[k] * launches_per_step[k] for k in kern)
             if loop_steps > 0:
                 # the timed steps ran inside tile_loop: ONE launch = loop_steps steps; its duration from events attached to
                 # that dispatch; algorithmic bytes per launch = the per-step figure x the steps the launch takes (the state
@@ -604,13 +614,16 @@ def main():
                 assert all(n == loop_steps for _, n in lt)
                 kern["tile_loop"] = float(np.median([ms for ms, _ in lt])) * 1e-3
                 algo["tile_loop"] = algo["tile_step"] * loop_steps
-            dom = "tile_loop" if loop_steps > 0 else max(kern, key=kern.get)
+            dom = "tile_loop" if loop_steps > 0 else max(kern, key=lambda k: kern[k] * launches_per_step[k])
             achieved = algo[dom] / kern[dom] / 1e9
             us_step = elapsed / args.steps * 1e6
             # what limits the kernel: HBM only if the algorithmic bytes move at a sizeable fraction of the measured copy rate
             if loop_steps > 0:
                 limiter = ("latency of the per-step chain inside the resident loop (wait for the neighbours' records -> deposit sweep -> "
                            "proposals -> exclusion -> publish); the state never leaves the chip between steps")
+            elif dom == "ntt_conv":
+                limiter = ("f64 issue of the modular butterflies (5 launches of an exact number-theoretic transform, 2 x 2^%d residues each) and the "
+                           "memory passes between them" % ntt["log2_m"])
             elif achieved >= 0.5 * hbm_copy:
                 limiter = "hbm"
             elif L_all * (32 + 8 * w["K"]) < 200e6:
@@ -632,7 +645,8 @@ def main():
                              "inside the resident loop the state stays in LDS between steps and only the records travel (counter traffic about a tenth, "
                              "profiles/r02_loop_config2_pmc.json): the fraction says how fast the steps go, not how busy HBM is") if loop_steps > 0 else
                             "algorithmic bytes = (32 + 8K) B per site + the deposits, per step",
-                    "deposits_per_step": dep_per_step, "kernels_per_step": len(kern) if loop_steps == 0 else 1.0 / loop_steps,
+                    "deposits_per_step": dep_per_step, "kernels_per_step": sum(launches_per_step.values()) if loop_steps == 0 else 1.0 / loop_steps,
+                    "launches_per_step": launches_per_step,
                     "steps_per_launch": loop_steps if loop_steps > 0 else 1}
         roof = dict(roof or {}, **{"hbm_copy_GBps": hbm_copy})
     if not sharded_path:

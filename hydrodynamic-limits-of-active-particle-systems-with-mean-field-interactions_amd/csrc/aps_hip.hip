@@ -2009,7 +2009,7 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
         t1 = h->p.periodic ? t1 + g : std::min(h->ts_ntile, t1 + g);
     }
     const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1, h->f32);
-    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total;
+    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h), h->ntt_on).total;
     const void *table_ptr = h->f32 ? (const void *)h->d_table_i : (const void *)h->d_table;
     void *args[] = {(void *)&a, (void *)&table_ptr};
     // a range that wraps around the torus (flush of a sharded periodic handle) is launched in pieces

@@ -56,7 +56,8 @@ __host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TS_WH 
 constexpr int TS_SHCAP = 320;              // windowed sweep: capacity of a shared class list (a round adds at most 256 entries); per side: half
 constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
 struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
-__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K, int wbytes = 8) {
+// no_table: the field arrives complete (deposits go to the convolution of ntt_conv.hpp): neither table nor windows in LDS
+__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K, int wbytes = 8, bool no_table = false) {
     TsLds l;
     const size_t TS = 64 * (size_t)RS;
     const int ncell = (int)(TS + 2) * K;
@@ -69,7 +70,7 @@ __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, i
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
     l.plist = l.misc + 128;
     l.tab = (l.plist + (l.cells_in_regs ? TS * (size_t)K * 8 : 0) + 15) / 16 * 16;
-    const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes;
+    const size_t table = no_table ? 0 : (tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes);
     const size_t red = (size_t)FU_WAVES * TS * 2 * wbytes;
     l.field = l.tab + red;                                      // fresh {W, S} of the frame sites, behind the partial sums
     const size_t after = red + TS * sizeof(double2);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     constexpr int NR = K1 ? ((TS + 2 + FU_WAVES - 1) / FU_WAVES + 63) / 64 : TS_CREG;   // register rounds of the wave's cell chunk
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
-    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K, WB);
+    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K, WB, a.dense != nullptr);
     char *lds_c = reinterpret_cast<char *>(lds);
     uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
     uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const 
     // The table goes straight into LDS (LDS-direct loads, 1 KB per wave instruction, no registers); the global copy is
     // followed by zeros, so the padded tail comes along.  Written as inline assembly like the windows below (the compiler
     // would put an s_waitcnt vmcnt(0) in front of every later LDS read); the wait in front of the barrier orders it.
-    if (TAB_LDS) {
+    if (TAB_LDS && !a.dense) {
         const int nchunk = ts_table_chunks(a.tlen, RS, OWN, WB);
         const char *srct = reinterpret_cast<const char *>(table_g) + lane * 16;
         for (int c = wave; c < nchunk; c += FU_WAVES) {

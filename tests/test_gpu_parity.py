@@ -947,8 +947,13 @@ def test_fp32_windowed_sweep_dense_buckets(capi, periodic):
     N = len(pos)
     orc = so.SyncOracle(par, dt=0.05, seed=5, sum_bits=29)
     orc.set_state(pos, spin)
-    h = make_handle(capi, par, N, dt=0.05, seed=5, method="tiles", fp32=True)
+    os.environ["APS_NTT"] = "0"                              # this test is about the sweep (between walls the convolution would take over)
     try:
+        h = make_handle(capi, par, N, dt=0.05, seed=5, method="tiles", fp32=True)
+    finally:
+        del os.environ["APS_NTT"]
+    try:
+        assert not h.ntt_info()["on"]
         info = h.tiles_info()
         assert not info["table_in_lds"], info
         tab, q = h.table()
@@ -1003,17 +1008,24 @@ def test_fp32_field_update_by_exact_convolution(capi, sigma, L):
         h.close()
 
 
-def test_fp32_config5_scale_against_oracle_windows(capi):
+@pytest.mark.parametrize("update", ["convolution", "sweep"])
+def test_fp32_config5_scale_against_oracle_windows(capi, update):
     """BASELINE config 5 as it is worded (N = 1e6, float32): the int32 field after 200 steps against the oracle's stencil
-    with the coarse table on wall / transition / interior windows, bit for bit."""
+    with the coarse table on wall / transition / interior windows, bit for bit -- the field kept by the exact convolution
+    (csrc/ntt_conv.hpp, the default at this size) and by the windowed sweep (APS_NTT=0)."""
     L, N = 2_000_000, 1_000_000
     par = LatticeGasParams.from_kwargs(L=L, xlim=1.0, rate_diffusion=0.02, rate_active=5.0, beta=0.7,
                                        scale_rates=False, local_kernel_sigma=0.005, site_capacity=1)
     rng = np.random.default_rng(12)
     pos = rng.choice(L, size=N, replace=False).astype(np.int32)
     spin = rng.choice(np.array([1, -1], np.int8), size=N)
-    h = make_handle(capi, par, N, dt=0.0125, seed=6, method="tiles", fp32=True)
+    os.environ["APS_NTT"] = "1" if update == "convolution" else "0"
     try:
+        h = make_handle(capi, par, N, dt=0.0125, seed=6, method="tiles", fp32=True)
+    finally:
+        del os.environ["APS_NTT"]
+    try:
+        assert h.ntt_info()["on"] == (update == "convolution")
         tab, q = h.table()
         otab, oq = so.build_table(par.sigma_grid, L, 1, False, 29)
         assert q == oq == 12 and np.array_equal(tab, otab[:len(tab)]) and len(tab) == 40001
