@@ -2632,6 +2632,9 @@ int aps_create(const aps_params *p, aps_handle **out) {
             const double miss = std::fabs(wgs - 2.4 * 256.0);
             if (miss < best) { best = miss; h->fu_R = rs; }
         }
+        // grids of many workgroups per CU (the streaming regime): 7 x 64 sites per workgroup (measured at N = 1.6e7, L = 3.2e7, whole step:
+        // R = 2 .. 8 -> 786, 664, 641, 697, 656, 630, 681 us)
+        if ((double)(((int64_t)p->L + 64 * 8 - 1) / (64 * 8)) * h->E > 8.0 * 256.0 && h->tlen <= 4096) h->fu_R = 7;
         if (const char *env = std::getenv("APS_FU_R")) { const int r = std::atoi(env); if (r >= 2 && r <= 8) h->fu_R = r; }
     }
     // A particle moves at most one site per step, so tile bounds drift by <= 1 per step: when nobody can die
