@@ -56,7 +56,7 @@ def step_algo_bytes(kernel, N, L, K, deposits, fp32=False):
 
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD32 x 2.4 GHz
 LDS_CYCLES_PER_64_PAIRS = 5.0  # measured (PMC 4.93): 4.5 per table gather (2.0 + 2.5 bank conflicts) + 0.5 source broadcast
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes, per workload
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes, per workload
 
 
 def measured_traffic_bytes(workload, kernel, steps_per_launch=1):
