@@ -46,8 +46,9 @@ ALGO_BYTES_PER_PARTICLE_STEP = 16.0   # SURVEY 8d (all-pairs): 4 B state read + 
 #   apply            N * (1 proposal + 4 state + 4 index) + C * (8 state/source word + 8 occupancy) + 4 D + 16 N / 64
 #   field_update     L * 32 ({W,S} read + write) + 4 D
 #   tile_step        L * (32 {W,S} read + write [16 with the 32-bit field]  +  8 K cell words read + write) + 8 D (deposit written, read) + 8 T (counters)
-def step_algo_bytes(kernel, N, L, K, deposits, fp32=False):
-    changed = 0.6 * deposits          # estimate (a hop makes 2 deposits, a flip or an exit 1); only `apply` uses it
+def step_algo_bytes(kernel, N, L, K, deposits, fp32=False, changed=None):
+    if changed is None:               # particles whose state a step changes; only `apply` uses it.  bench.py counts them (one step, states compared)
+        changed = 0.6 * deposits
     return {"propose_lattice": 37.0 * N + 4.0 * L,
             "apply": 9.25 * N + 16.0 * changed + 4.0 * deposits,
             "field_update": 32.0 * L + 4.0 * deposits,
@@ -597,7 +598,14 @@ def main():
             bracketed = os.environ.get("APS_PROF_BRACKET") is not None
             dep_per_step = deposits / max(n_fu, 1)
             N_all, L_all = w["N"] * n_ens, w["L"] * n_ens
-            algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32"))) for k in kern}
+            changed = None
+            if "apply" in kern:                          # accepted events of one step, counted: the states before and after compared
+                before = [h.get_state(ensemble=e) for e in range(n_ens)]
+                h.step(1)
+                changed = float(sum(int(((x[0] != y[0]) | (x[1] != y[1]) | (x[2] != y[2]) | (x[3] != y[3])).sum())
+                                    for x, y in zip(before, [h.get_state(ensemble=e) for e in range(n_ens)])))
+                del before
+            algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32")), changed) for k in kern}
             launches_per_step = {k: 1 for k in kern}
             if "ntt_conv" in kern:
                 # per launch: both signals of 2^m residues read and written (4 B each); per step on top: the deposit signals read
@@ -645,7 +653,7 @@ def main():
                              "inside the resident loop the state stays in LDS between steps and only the records travel (counter traffic about a tenth, "
                              "profiles/r02_loop_config2_pmc.json): the fraction says how fast the steps go, not how busy HBM is") if loop_steps > 0 else
                             "algorithmic bytes = (32 + 8K) B per site + the deposits, per step",
-                    "deposits_per_step": dep_per_step, "kernels_per_step": sum(launches_per_step.values()) if loop_steps == 0 else 1.0 / loop_steps,
+                    "deposits_per_step": dep_per_step, "changed_particles_per_step": changed, "kernels_per_step": sum(launches_per_step.values()) if loop_steps == 0 else 1.0 / loop_steps,
                     "launches_per_step": launches_per_step,
                     "steps_per_launch": loop_steps if loop_steps > 0 else 1}
         roof = dict(roof or {}, **{"hbm_copy_GBps": hbm_copy})
