@@ -2120,10 +2120,19 @@ template <bool F32>
 const void *tl_kernel_f(bool periodic, int RS, bool k1) {
 #define TL_PICK(BC, R) (k1 ? (const void *)&tile_loop<BC, R, true, F32> : (const void *)&tile_loop<BC, R, false, F32>)
 #define TL_CASE(R) case R: return periodic ? TL_PICK(1, R) : TL_PICK(0, R);
+    // binary64 frames that do not fit 256 VGPRs (they would spill to scratch) are not built: 8 x 64 sites, and 7 x 64 with K > 1 -- such handles
+    // step with one launch per step ("no kernel for this frame")
+    if (!F32 && (RS == 8 || (RS == 7 && !k1))) return nullptr;
 #ifdef APS_DEV_RS
     switch (RS) { TL_CASE(APS_DEV_RS) default: return nullptr; }
 #else
-    switch (RS) { TL_CASE(1) TL_CASE(2) TL_CASE(3) TL_CASE(4) TL_CASE(5) TL_CASE(6) TL_CASE(7) TL_CASE(8) default: return nullptr; }
+    if constexpr (F32) { if (RS == 8) return periodic ? TL_PICK(1, 8) : TL_PICK(0, 8); }
+    switch (RS) {
+        TL_CASE(1) TL_CASE(2) TL_CASE(3) TL_CASE(4) TL_CASE(5) TL_CASE(6)
+        case 7: return k1 ? (periodic ? (const void *)&tile_loop<1, 7, true, F32> : (const void *)&tile_loop<0, 7, true, F32>)
+                          : (F32 ? (periodic ? (const void *)&tile_loop<1, 7, false, true> : (const void *)&tile_loop<0, 7, false, true>) : nullptr);
+        default: return nullptr;
+    }
 #endif
 #undef TL_CASE
 #undef TL_PICK

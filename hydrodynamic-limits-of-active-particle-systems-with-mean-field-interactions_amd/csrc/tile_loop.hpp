@@ -74,7 +74,9 @@ __device__ __forceinline__ void tl_lds_add(double *p, double v) { unsafeAtomicAd
 __device__ __forceinline__ void tl_lds_add(int *p, int v) { atomicAdd(p, v); }
 
 template <int BC, int RS, bool K1, bool F32>
-__global__ __launch_bounds__(FU_THREADS, (RS >= 6 && !F32) ? 2 : 3) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
+// (two waves per SIMD for every instance: the loop runs with exactly two workgroups per CU where the geometry is chosen for it, and at three the
+// smaller frames spilled up to 200 bytes per lane to scratch)
+__global__ __launch_bounds__(FU_THREADS, 2) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
     using W = typename TsField<F32>::w_t;
     using WS = typename TsField<F32>::ws_t;
     constexpr int SH = TsField<F32>::SH, WB = (int)sizeof(W);

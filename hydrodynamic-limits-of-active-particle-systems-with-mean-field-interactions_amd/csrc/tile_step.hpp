@@ -242,9 +242,14 @@ __device__ __forceinline__ void ts_image_group(const uint4 q, const uint32_t (&x
     }
 }
 
+#ifdef APS_TS_WAVES                        /* tuning builds: pin the waves per SIMD the register allocator aims for */
+#define TS_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(APS_TS_WAVES, APS_TS_WAVES)))
+#else
+#define TS_WAVES_ATTR
+#endif
 // K1: site capacity 1 (one cell per site): every loop over a site's cells disappears
 template <int BC, bool TAB_LDS, int RS, bool K1, bool F32>
-__global__ __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const void *__restrict__ table_v) {
+__global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const TileArgs a, const void *__restrict__ table_v) {
     using W = typename TsField<F32>::w_t;
     using WS = typename TsField<F32>::ws_t;
     constexpr int SH = TsField<F32>::SH, WB = (int)sizeof(W);
