@@ -1008,6 +1008,44 @@ def test_fp32_field_update_by_exact_convolution(capi, sigma, L):
         h.close()
 
 
+def test_fp32_convolution_with_ensembles_anchors_and_exits(capi):
+    """The convolution path (forced, APS_NTT=1) on a handle of three ensembles with anchors, bind / unbind and exits (an exit is a
+    deposit like any other: -1 in c_W, -sigma in c_S), K = 2: every ensemble against its own oracle after blocks of steps -- state,
+    exit log, {W, S, occupancy} on all sites."""
+    betas = [0.4, 1.3, 2.2]
+    kw = dict(L=20000, K=2, sigma=0.01, rate_diffusion=2.0, anchor_positions=[0.3, 0.7], anchor_radius=0.02, k_on=2.0, k_off=1.0, k_exit=0.8)
+    par0 = params(**kw)
+    rng = np.random.default_rng(9)
+    N = 15000
+    states = [random_state(rng, par0.L, N, par0.K) for _ in betas]
+    os.environ["APS_NTT"] = "1"
+    try:
+        h = make_handle(capi, par0, N, dt=0.04, seed=12, method="tiles", fp32=True, beta=betas)
+    finally:
+        del os.environ["APS_NTT"]
+    orcs = []
+    for e, b in enumerate(betas):
+        orc = so.SyncOracle(params(beta=b, **kw), dt=0.04, seed=12, ensemble=e, sum_bits=29)
+        orc.set_state(*states[e])
+        orcs.append(orc)
+    try:
+        assert h.ntt_info()["on"]
+        for e, (p, s) in enumerate(states):
+            h.set_state(p, s, ensemble=e)
+        for n in (3, 30):
+            h.step(n)
+            for e, orc in enumerate(orcs):
+                orc.run(n)
+                got = h.get_state(ensemble=e)
+                assert np.array_equal(got[0], orc.pos) and np.array_equal(got[1], orc.spin) and np.array_equal(got[2], orc.bound) and np.array_equal(got[3], orc.alive), (n, e)
+                check_lattice(h, orc, ensemble=e)
+        assert any((orc.alive == 0).any() for orc in orcs)
+        for e, orc in enumerate(orcs):
+            assert np.array_equal(h.exits(ensemble=e), orc.exits())
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("update", ["convolution", "sweep"])
 def test_fp32_config5_scale_against_oracle_windows(capi, update):
     """BASELINE config 5 as it is worded (N = 1e6, float32): the int32 field after 200 steps against the oracle's stencil
