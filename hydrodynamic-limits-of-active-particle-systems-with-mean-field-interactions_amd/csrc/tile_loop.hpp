@@ -24,6 +24,9 @@
 constexpr int TL_SEG_MIN = 88;             // the four pooled deposit lists hold 4 (seg + 4) entries each; 88 at least (three workgroups per CU at config 2's 37 KB
                                            // table: <= 42 LDS granules of 1280 B), the host takes up to 256 when the residency the grid needs leaves room
 constexpr int TL_NG = 2;                   // bucket groups whose first page a wave asks for ahead of time (config 2 has two)
+#ifndef TL_MIN_WAVES
+#define TL_MIN_WAVES 2                     /* waves per SIMD the register allocator must leave room for (tuning builds may ask for more) */
+#endif
 constexpr int TL_ABORT = 31;               // misc word: this workgroup leaves (a wait ran out, here or elsewhere)
 
 struct LoopArgs {
@@ -76,7 +79,7 @@ __device__ __forceinline__ void tl_lds_add(int *p, int v) { atomicAdd(p, v); }
 template <int BC, int RS, bool K1, bool F32>
 // (two waves per SIMD for every instance: the loop runs with exactly two workgroups per CU where the geometry is chosen for it, and at three the
 // smaller frames spilled up to 200 bytes per lane to scratch)
-__global__ __launch_bounds__(FU_THREADS, 2) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
+__global__ __launch_bounds__(FU_THREADS, TL_MIN_WAVES) void tile_loop(const LoopArgs la, const void *__restrict__ table_v) {
     using W = typename TsField<F32>::w_t;
     using WS = typename TsField<F32>::ws_t;
     constexpr int SH = TsField<F32>::SH, WB = (int)sizeof(W);
