@@ -2108,6 +2108,8 @@ int ntt_setup(aps_handle *h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_what, spec.data(), M * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_ntt_sig, 0, (size_t)h->E * 2 * M * 4, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // {W, S} need no second buffer: the tile kernel only reads them and the last sweep of the convolution updates them in place
+    if (h->d_wsi[1] && h->d_wsi[1] != h->d_wsi[0]) { (void)hipFree(h->d_wsi[1]); h->d_wsi[1] = h->d_wsi[0]; }
     h->ntt_on = true;
     return APS_OK;
 }
@@ -2756,7 +2758,7 @@ void aps_destroy(aps_handle *h) {
     if (h->h_ipc_err) (void)hipHostFree(h->h_ipc_err);
     for (hipEvent_t ev : h->loop_ev) if (ev) (void)hipEventDestroy(ev);
     for (void *q : {(void *)h->d_xrec, (void *)h->d_abort}) if (q) (void)hipFree(q);
-    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)h->d_wsi[1],
+    for (void *q : {(void *)h->d_slot_of, (void *)h->d_model, (void *)h->d_rare, (void *)h->d_table_i, (void *)h->d_wsi[0], (void *)(h->d_wsi[1] == h->d_wsi[0] ? nullptr : h->d_wsi[1]),
                     (void *)h->d_halo_send[0], (void *)h->d_halo_send[1], (void *)h->d_halo_recv[0], (void *)h->d_halo_recv[1], (void *)h->d_halo_seg_send[0],
                     (void *)h->d_halo_seg_send[1], (void *)h->d_halo_seg_recv[0], (void *)h->d_halo_seg_recv[1]}) if (q) (void)hipFree(q);
     for (void *q : {(void *)h->d_ref, (void *)h->d_cnt_pm, (void *)h->d_block_table, (void *)h->d_scal, (void *)h->d_lo_hi, (void *)h->d_ref_ok, (void *)h->d_ws, (void *)h->d_occ_site, (void *)h->d_dcnt, (void *)h->d_dep, (void *)h->d_stepw}) if (q) (void)hipFree(q);

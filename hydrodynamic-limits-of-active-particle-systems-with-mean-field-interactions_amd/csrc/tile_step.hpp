@@ -666,7 +666,8 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
             for (int w = 0; w < FU_WAVES; ++w) { const WS pth = red[(size_t)w * TS + xi]; f.x += pth.x; f.y += pth.y; }
             // S / W does not care about the unit (2^-q in the integer field): the proposals read doubles either way
             fieldL[xi] = a.field_mode ? make_double2((double)f.x, (double)f.y) : make_double2((double)misc[5], (double)misc[4]);
-            if (a.field_mode && xi >= 2 && xi < 2 + own_n) reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
+            // (dense: {W, S} live in ONE buffer that the convolution updates in place -- nothing to carry over to the other parity)
+            if (a.field_mode && !a.dense && xi >= 2 && xi < 2 + own_n) reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
         }
     }
     if (a.field_only) return;                                  // flush of the pending deposits only (observation)
@@ -719,61 +720,92 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
     uint32_t *dep_o = a.dep_out + ((size_t)e * a.ntile + tile) * a.dcap;
     uint32_t *cell_o = a.cell_out + (size_t)e * L * K;
     int my_spin = 0, my_live = 0;
+    // the deposits of one event: into the tile's list, or (dense) into the coefficient signals of the convolution, wall images included
+    auto emit_deposits = [&](const int nd, const uint32_t d0, const uint32_t d1) {
+        if (!nd || !a.field_mode) return;
+        if (a.dense) {
+            int *cw_sig = a.dense + ((size_t)e << (a.dense_m + 1)), *cs_sig = cw_sig + ((size_t)1 << a.dense_m);
+            for (int u = 0; u < nd; ++u) {
+                const uint32_t d = u ? d1 : d0;
+                const int ds_ = (int)(d & POS_MASK), cw = (int)((d >> 27) & 3u) - 1, cs = (int)(d >> 29) - 2;
+                const int at = ds_ + a.dense_rt;
+                if (cw) atomicAdd(cw_sig + at, cw);
+                atomicAdd(cs_sig + at, cs);
+                const int img = ds_ < a.dense_rt ? a.dense_rt - 1 - ds_ : (ds_ >= L - a.dense_rt ? 2 * L - 1 - ds_ + a.dense_rt : -1);
+                if (img >= 0) { if (cw) atomicAdd(cw_sig + img, cw); atomicAdd(cs_sig + img, cs); }
+            }
+        } else {
+            const int kd = atomicAdd(&misc[0], nd);
+            if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
+        }
+    };
+    // the event of the particle `c` on site s (frame position xi): returns whether it is still on the site afterwards (c updated);
+    // hop_granted: the exclusion rule let its hop to frame position j through
+    auto own_event = [&](uint32_t &c, const int ev, const int s, const int j, const bool hop_granted) -> bool {
+        const int sgn = (c & CELL_PLUS) ? 1 : -1;
+        uint32_t d0 = 0, d1 = 0;
+        int nd = 0;
+        bool stays = true;
+        if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
+            if (hop_granted) { stays = false; d0 = deposit(s, -1, -sgn); d1 = deposit(frame_site(j), 1, sgn); nd = 2; }
+        } else if (ev == EV_BIND) c |= CELL_BOUND;
+        else if (ev == EV_UNBIND) c &= ~CELL_BOUND;
+        else if (ev == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
+        else if (ev == EV_EXIT) {
+            stays = false;
+            const TileRare R = *a.rare;
+            if (tile >= R.rec_lo && tile < R.rec_hi) {
+                const unsigned kx = atomicAdd(&R.n_exit[e], 1u);
+                if ((int)kx < R.exit_cap) {
+                    double *row = R.exit_log + ((size_t)e * R.exit_cap + kx) * 3;
+                    row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
+                }
+                R.src[(size_t)e * R.Npad + R.slot_of[(size_t)e * R.N + (c & CELL_ID)]] =
+                    (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
+            }
+            d0 = deposit(s, -1, -sgn); nd = 1;
+        }
+        emit_deposits(nd, d0, d1);
+        return stays;
+    };
 #pragma unroll
     for (int r = 0; r < NOLD; ++r) {
         const int xi = r * FU_THREADS + t;
         if (xi < 2 || xi >= 2 + own_n || xi >= TS) continue;
         const int s = frame_site(xi);
         uint32_t *out = cell_o + (unsigned)s * (unsigned)K;
+        if constexpr (K1) {
+            // One cell per site: a hop is only ever proposed into a site that was empty at the start of the step (channels(): open_l /
+            // open_r), so its capacity is 1 and the only rival is the particle on the far side of the target -- the rule of DESIGN 3
+            // (smaller id wins) on a window of five sites, read once (tile_loop's K = 1 path; 10 LDS reads instead of ~24)
+            const uint32_t cm2 = cellL[xi - 1], cm1 = cellL[xi], c0 = cellL[xi + 1], cp1 = cellL[xi + 2], cp2 = cellL[xi + 3];
+            const int pm2 = propL[xi - 2] & 7, pm1 = propL[xi - 1] & 7, p0 = propL[xi] & 7, pp1 = propL[xi + 1] & 7, pp2 = xi + 2 < TS ? propL[xi + 2] & 7 : 0;
+            const bool from_l2 = cm2 != CELL_EMPTY && (pm2 == EV_RIGHT || pm2 == EV_FWD);     // the particle two sites left wants xi - 1
+            const bool from_l1 = cm1 != CELL_EMPTY && (pm1 == EV_RIGHT || pm1 == EV_FWD);     // the left neighbour wants this site
+            const bool from_r1 = cp1 != CELL_EMPTY && pp1 == EV_LEFT;                          // the right neighbour wants this site
+            const bool from_r2 = cp2 != CELL_EMPTY && pp2 == EV_LEFT;                          // the particle two sites right wants xi + 1
+            uint32_t newc = CELL_EMPTY;
+            if (c0 != CELL_EMPTY) {
+                uint32_t c = c0;
+                const bool left = p0 == EV_LEFT;
+                const bool granted = left ? !(from_l2 && (cm2 & CELL_ID) < (c & CELL_ID)) : !(from_r2 && (cp2 & CELL_ID) < (c & CELL_ID));
+                if (own_event(c, p0, s, left ? xi - 1 : xi + 1, granted)) newc = c;
+            }
+            if (from_l1 && !(from_r1 && (cp1 & CELL_ID) < (cm1 & CELL_ID))) newc = cm1;        // granted arrivals (this site was empty)
+            if (from_r1 && !(from_l1 && (cm1 & CELL_ID) < (cp1 & CELL_ID))) newc = cp1;
+            out[0] = newc;
+            if (newc != CELL_EMPTY) { my_spin += (newc & CELL_PLUS) ? 1 : -1; my_live += 1; }
+            continue;
+        }
         int n_out = 0;
         for (int k = 0; k < K; ++k) {                          // the particles on this site: stay (possibly changed) or leave
             uint32_t c = cellL[(xi + 1) * K + k];
             if (c == CELL_EMPTY) continue;
-            const int ev = propL[xi * K + k] & 7, sgn = (c & CELL_PLUS) ? 1 : -1;
-            uint32_t d0 = 0, d1 = 0;
-            int nd = 0;
-            bool stays = true;
-            if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
-                const int j = ev == EV_LEFT ? xi - 1 : xi + 1;
-                if (rank_at(j, c & CELL_ID) < cap_at(j)) {
-                    stays = false;
-                    d0 = deposit(s, -1, -sgn); d1 = deposit(frame_site(j), 1, sgn); nd = 2;
-                }
-            } else if (ev == EV_BIND) c |= CELL_BOUND;
-            else if (ev == EV_UNBIND) c &= ~CELL_BOUND;
-            else if (ev == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
-            else if (ev == EV_EXIT) {
-                stays = false;
-                const TileRare R = *a.rare;
-                if (tile >= R.rec_lo && tile < R.rec_hi) {
-                    const unsigned kx = atomicAdd(&R.n_exit[e], 1u);
-                    if ((int)kx < R.exit_cap) {
-                        double *row = R.exit_log + ((size_t)e * R.exit_cap + kx) * 3;
-                        row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
-                    }
-                    R.src[(size_t)e * R.Npad + R.slot_of[(size_t)e * R.N + (c & CELL_ID)]] =
-                        (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
-                }
-                d0 = deposit(s, -1, -sgn); nd = 1;
-            }
-            if (stays) { out[n_out++] = c; my_spin += (c & CELL_PLUS) ? 1 : -1; my_live += 1; }
-            if (nd && a.field_mode) {
-                if (a.dense) {                                 // coefficient signals of the convolution, wall images included
-                    int *cw_sig = a.dense + ((size_t)e << (a.dense_m + 1)), *cs_sig = cw_sig + ((size_t)1 << a.dense_m);
-                    for (int u = 0; u < nd; ++u) {
-                        const uint32_t d = u ? d1 : d0;
-                        const int ds_ = (int)(d & POS_MASK), cw = (int)((d >> 27) & 3u) - 1, cs = (int)(d >> 29) - 2;
-                        const int at = ds_ + a.dense_rt;
-                        if (cw) atomicAdd(cw_sig + at, cw);
-                        atomicAdd(cs_sig + at, cs);
-                        const int img = ds_ < a.dense_rt ? a.dense_rt - 1 - ds_ : (ds_ >= L - a.dense_rt ? 2 * L - 1 - ds_ + a.dense_rt : -1);
-                        if (img >= 0) { if (cw) atomicAdd(cw_sig + img, cw); atomicAdd(cs_sig + img, cs); }
-                    }
-                } else {
-                    const int kd = atomicAdd(&misc[0], nd);
-                    if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
-                }
-            }
+            const int ev = propL[xi * K + k] & 7;
+            const bool hop = ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD;
+            const int j = ev == EV_LEFT ? xi - 1 : xi + 1;
+            const bool granted = hop && rank_at(j, c & CELL_ID) < cap_at(j);
+            if (own_event(c, ev, s, j, granted)) { out[n_out++] = c; my_spin += (c & CELL_PLUS) ? 1 : -1; my_live += 1; }
         }
         const int cap = cap_at(xi);
         for (int k = 0; k < K; ++k) {                          // granted arrivals from the left and right neighbour
