@@ -593,7 +593,7 @@ def main():
             # around the launch instead, which read ~2 us more per kernel (the event packets' own cost).
             kern = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}
             ntt = h.ntt_info()
-            if ntt["on"] and ntt["prof_launches"]:     # the field update as an exact convolution (csrc/ntt_conv.hpp): five launches per step
+            if ntt["on"] and ntt["prof_launches"]:     # the field update as an exact convolution (csrc/ntt_conv.hpp): three (five) launches per step
                 kern["ntt_conv"] = ntt["prof_ms"] / ntt["prof_launches"] * 1e-3
             bracketed = os.environ.get("APS_PROF_BRACKET") is not None
             dep_per_step = deposits / max(n_fu, 1)
@@ -630,8 +630,8 @@ def main():
                 limiter = ("latency of the per-step chain inside the resident loop (wait for the neighbours' records -> deposit sweep -> "
                            "proposals -> exclusion -> publish); the state never leaves the chip between steps")
             elif dom == "ntt_conv":
-                limiter = ("f64 issue of the modular butterflies (5 launches of an exact number-theoretic transform, 2 x 2^%d residues each) and the "
-                           "memory passes between them" % ntt["log2_m"])
+                limiter = ("f64 issue of the modular butterflies (%d launches of an exact number-theoretic transform, 2 x 2^%d residues each) and the "
+                           "memory passes between them" % (ntt["launches"], ntt["log2_m"]))
             elif achieved >= 0.5 * hbm_copy:
                 limiter = "hbm"
             elif L_all * (32 + 8 * w["K"]) < 200e6:

@@ -131,6 +131,7 @@ def load():
         "aps_exchange_kind": (C.c_int, [vp]),
         "aps_set_flip_table": (C.c_int, [vp, vp, i32]),
         "aps_ntt_info": (C.c_int, [vp, P(i32), P(i32), P(dbl), P(i64)]),
+        "aps_ntt_launches": (C.c_int, [vp]),
         "aps_tiles_info": (C.c_int, [vp, P(i32), P(i32), P(i32), P(i32)]),
     }
     lenient = os.environ.get("APS_LIB_LENIENT") == "1"     # tuning tools that load an older build of the library for A/B timing
@@ -319,10 +320,10 @@ class Handle:
         self._ck(self.lib.aps_set_flip_table(self._h, _ptr(tab), tab.shape[1] - 1))
 
     def ntt_info(self):
-        """dict(on, log2_m, prof_ms, prof_launches): does this handle update the field by the exact convolution (aps_ntt_info)"""
+        """dict(on, log2_m, prof_ms, prof_launches, launches): does this handle update the field by the exact convolution (aps_ntt_info)"""
         on, m, ms, n = C.c_int32(), C.c_int32(), C.c_double(), C.c_int64()
         self._ck(self.lib.aps_ntt_info(self._h, C.byref(on), C.byref(m), C.byref(ms), C.byref(n)))
-        return dict(on=bool(on.value), log2_m=m.value, prof_ms=ms.value, prof_launches=n.value)
+        return dict(on=bool(on.value), log2_m=m.value, prof_ms=ms.value, prof_launches=n.value, launches=int(self.lib.aps_ntt_launches(self._h)))
 
     def tiles_info(self):
         """dict(frame_sites, owned_sites, n_tiles, table_in_lds) of a tiles handle (aps_tiles_info)."""

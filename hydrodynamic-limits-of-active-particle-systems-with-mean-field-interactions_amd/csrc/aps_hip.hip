@@ -1489,7 +1489,7 @@ struct aps_handle {
     bool f32 = false, ws_view_stale = false;
     double *d_flip_tab = nullptr;              // aps_set_flip_table
     // the field update as an exact number-theoretic convolution (ntt_conv.hpp): 32-bit field, table beyond LDS, one rank, walls
-    bool ntt_on = false;
+    bool ntt_on = false, ntt_fused = false;
     NttPlan ntt{};
     uint32_t *d_ntt_sig = nullptr, *d_ntt_tab = nullptr;       // [E][2][M] residues; all the tables in one allocation
     int *d_ntt_csig = nullptr;                                 // [E][2][M] deposit coefficients of the step (index = site + Rt), cleared by the transform
@@ -2041,6 +2041,15 @@ int launch_ntt_conv(aps_handle *h) {
     const bool timed = h->profiling && h->prof_dispatch;
 #define NTT_STRIDED(AXIS, INV, A_, CSIG, WS, FLAG) do { if ((rc = prof_mark(h, KIND_NTT))) return rc; \
         ntt_launch_strided<AXIS, INV>(A_, grid, block, h->stream, h->k_start, h->k_stop, timed, pl, h->d_ntt_sig, CSIG, WS, FLAG); } while (0)
+    if (h->ntt_fused) {                                         // i2 sweep, the whole middle in one launch, i2 sweep back
+        NTT_STRIDED(2, false, pl.a2, h->d_ntt_csig, (int2 *)nullptr, 1);
+        if ((rc = prof_mark(h, KIND_NTT))) return rc;
+        APS_K(h, ntt_mid, dim3(1u << pl.a2, 2u, (unsigned)h->E), dim3(NTT_MID_THREADS), NTT_MID_LDS, pl, h->d_ntt_sig, pl.whatp);
+        NTT_STRIDED(2, true, pl.a2, (int *)nullptr, h->d_wsi[out], 1);
+        HIP_TRY(h, hipGetLastError());
+        h->field_pending = false;
+        return APS_OK;
+    }
     if (pl.a2 > 0) {
         NTT_STRIDED(2, false, pl.a2, h->d_ntt_csig, (int2 *)nullptr, 1);
         NTT_STRIDED(1, false, pl.a1, (int *)nullptr, (int2 *)nullptr, 0);
@@ -2079,14 +2088,14 @@ int ntt_setup(aps_handle *h) {
     NttTables T;
     ntt_build_tables(m, T);
     const size_t M = (size_t)1 << m;
-    const size_t o_wr = 0, o_t1 = o_wr + T.wr.size(), o_hi = o_t1 + T.t1.size(), o_lo = o_hi + T.t2hi.size(), o_what = o_lo + T.t2lo.size(), total = o_what + M;
+    const size_t o_wr = 0, o_t1 = o_wr + T.wr.size(), o_hi = o_t1 + T.t1.size(), o_lo = o_hi + T.t2hi.size(), o_what = o_lo + T.t2lo.size(), o_whatp = o_what + M, total = o_whatp + M;
     int rc;
     if ((rc = dev_alloc(h, &h->d_ntt_tab, total)) || (rc = dev_alloc(h, &h->d_ntt_sig, (size_t)h->E * 2 * M)) || (rc = dev_alloc(h, &h->d_ntt_csig, (size_t)h->E * 2 * M))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_wr, T.wr.data(), T.wr.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_t1, T.t1.data(), T.t1.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_hi, T.t2hi.data(), T.t2hi.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_lo, T.t2lo.data(), T.t2lo.size() * 4, hipMemcpyHostToDevice, h->stream));
-    pl.wr = h->d_ntt_tab + o_wr; pl.t1 = h->d_ntt_tab + o_t1; pl.t2hi = h->d_ntt_tab + o_hi; pl.t2lo = h->d_ntt_tab + o_lo; pl.what = h->d_ntt_tab + o_what;
+    pl.wr = h->d_ntt_tab + o_wr; pl.t1 = h->d_ntt_tab + o_t1; pl.t2hi = h->d_ntt_tab + o_hi; pl.t2lo = h->d_ntt_tab + o_lo; pl.what = h->d_ntt_tab + o_what; pl.whatp = h->d_ntt_tab + o_whatp;
     // spectrum of the table: w(|d|) at index d mod M, forward sweeps only, times 1 / M
     std::vector<uint32_t> wext(2 * M, 0u);
     for (int t = 0; t < h->tlen; ++t) {
@@ -2106,6 +2115,23 @@ int ntt_setup(aps_handle *h) {
     const uint32_t minv = ntt_powmod((uint32_t)(M % NTT_P), NTT_P - 2ull);
     for (size_t i = 0; i < M; ++i) spec[i] = ntt_mulmod_u64(spec[i], minv);
     HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_what, spec.data(), M * 4, hipMemcpyHostToDevice, h->stream));
+    // the three middle launches as one (ntt_mid): 128 x 128 slabs, at least two of them; APS_NTT_FUSED=0 keeps the five launches
+    const char *fenv = std::getenv("APS_NTT_FUSED");
+    h->ntt_fused = pl.a0 == 7 && pl.a1 == 7 && pl.a2 >= 1 && !(fenv && fenv[0] == '0');
+    std::vector<uint32_t> specp;
+    if (h->ntt_fused) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_MID_LDS) != hipSuccess) {
+            (void)hipGetLastError(); h->ntt_fused = false;
+        }
+    }
+    if (h->ntt_fused) {                                         // the spectrum in the slots' order: slot s holds frequency brev(s)
+        specp.resize(M);
+        auto brev7 = [](size_t v) { size_t r = 0; for (int b = 0; b < 7; ++b) r |= ((v >> b) & 1) << (6 - b); return r; };
+        for (size_t k2 = 0; k2 < (M >> 14); ++k2)
+            for (size_t s0 = 0; s0 < 128; ++s0)
+                for (size_t s1 = 0; s1 < 128; ++s1) specp[(k2 << 14) + s0 * 128 + s1] = spec[(k2 << 14) + brev7(s1) * 128 + brev7(s0)];
+        HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_whatp, specp.data(), M * 4, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(h, hipMemsetAsync(h->d_ntt_sig, 0, (size_t)h->E * 2 * M * 4, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // {W, S} need no second buffer: the tile kernel only reads them and the last sweep of the convolution updates them in place
@@ -3180,6 +3206,10 @@ int aps_ntt_info(aps_handle *h, int32_t *on, int32_t *log2_m, double *prof_ms, i
     if (prof_ms) *prof_ms = h->prof_ntt_ms;
     if (prof_launches) *prof_launches = h->prof_ntt_n;
     return APS_OK;
+}
+int aps_ntt_launches(aps_handle *h) {
+    if (!h || !h->ntt_on) return 0;
+    return h->ntt_fused ? 3 : h->ntt.a2 > 0 ? 5 : 3;
 }
 
 int aps_mark_reference(aps_handle *h, int32_t e) {

@@ -257,6 +257,10 @@ int aps_set_flip_table(aps_handle *h, const double *table, int32_t n);
  * table entries.  on: whether this handle does (APS_NTT=0 keeps the sweep, APS_NTT=1 takes the convolution for tables that fit
  * LDS as well); prof_ms / prof_launches: summed duration and number of the convolution's launches in the last aps_step_profile. */
 int aps_ntt_info(aps_handle *h, int32_t *on, int32_t *log2_m, double *prof_ms, int64_t *prof_launches);
+/* Launches per convolution: 3 when the transform has at least two 128 x 128 slabs (log2_m >= 15: sweep along the slab index, ONE
+ * launch for everything inside a slab -- two sweeps, the product with the table's spectrum, two sweeps back -- in LDS, sweep back;
+ * APS_NTT_FUSED=0 keeps them apart), 5 otherwise (3 at log2_m = 14, a single slab); 0 when the handle does not take the convolution. */
+int aps_ntt_launches(aps_handle *h);
 
 /* Geometry of a TILES handle: sites per workgroup frame (64 RS), sites a tile owns, number of tiles, whether the weight table
  * sits in LDS (else: windows of it, tile_step's windowed sweep). */

@@ -971,13 +971,16 @@ def test_fp32_windowed_sweep_dense_buckets(capi, periodic):
         h.close()
 
 
-@pytest.mark.parametrize("sigma,L", [(0.02, 90000), (0.004, 16000), (0.1, 120000)], ids=["m17", "m14_two_sweeps", "m18_beyond_lds"])
-def test_fp32_field_update_by_exact_convolution(capi, sigma, L):
+@pytest.mark.parametrize("sigma,L,fused", [(0.02, 90000, "1"), (0.02, 90000, "0"), (0.004, 16000, "1"), (0.1, 120000, "1")],
+                         ids=["m17", "m17_five_launches", "m14_two_sweeps", "m18_beyond_lds"])
+def test_fp32_field_update_by_exact_convolution(capi, sigma, L, fused):
     """csrc/ntt_conv.hpp: the step's deposits -> W, S of all sites by ONE number-theoretic convolution (mod 15 * 2^27 + 1, length
     2^m >= L + 2 reach, wall images entered as mirrored deposits) instead of the sweep -- exact integers, so state after every
     block and {W, S, occupancy} on ALL sites must equal the oracle's (which knows nothing of transforms) bit for bit.  Forced by
     APS_NTT=1 for tables that fit LDS (the first two cases: transforms of three and of two sweeps); the third is beyond LDS and
-    takes the convolution by itself.  Dense clusters at both walls and inside, K = 3, a thin background."""
+    takes the convolution by itself.  From m = 15 on the three middle launches are one (ntt_mid: a 128 x 128 slab per workgroup);
+    APS_NTT_FUSED=0 keeps the five launches, which m = 14 always takes.  Dense clusters at both walls and inside, K = 3, a thin
+    background."""
     par = params(L=L, K=3, sigma=sigma, rate_diffusion=3.0)
     rng = np.random.default_rng(2)
     sites = np.concatenate([rng.integers(L // 4, L // 4 + 1500, 2500), rng.integers(0, L, 1500), np.arange(L - 300, L), np.arange(0, 200)])
@@ -988,13 +991,15 @@ def test_fp32_field_update_by_exact_convolution(capi, sigma, L):
     orc = so.SyncOracle(par, dt=0.05, seed=7, sum_bits=29)
     orc.set_state(pos, spin)
     os.environ["APS_NTT"] = "1"
+    os.environ["APS_NTT_FUSED"] = fused
     try:
         h = make_handle(capi, par, N, dt=0.05, seed=7, method="tiles", fp32=True)
     finally:
-        del os.environ["APS_NTT"]
+        del os.environ["APS_NTT"], os.environ["APS_NTT_FUSED"]
     try:
         info = h.ntt_info()
         assert info["on"] and (1 << info["log2_m"]) >= L + 2 * (len(h.table()[0]) - 1), info
+        assert info["launches"] == (3 if fused == "1" and info["log2_m"] >= 15 else 5 if info["log2_m"] >= 15 else 3), info
         h.set_state(pos, spin)
         check_lattice(h, orc)
         for block, n in enumerate((1, 2, 37)):               # single steps and graph replay
