@@ -14,7 +14,7 @@ SRC = os.path.join(HERE, "csrc", "aps_hip.hip")
 SRCS = [SRC, os.path.join(HERE, "csrc", "pde_hip.hip"), os.path.join(HERE, "csrc", "gillespie_hip.hip"),
         os.path.join(HERE, "csrc", "gillespie_big_hip.hip")]   # stepper; PDE solver; exact event loop
 HDR = os.path.join(ROOT, "include", "aps.h")
-HDRS = [HDR, os.path.join(ROOT, "include", "pde.h"), os.path.join(HERE, "csrc", "aps_common.hpp"), os.path.join(HERE, "csrc", "tile_step.hpp"), os.path.join(HERE, "csrc", "tile_loop.hpp"), os.path.join(HERE, "csrc", "ntt_conv.hpp"),
+HDRS = [HDR, os.path.join(ROOT, "include", "pde.h"), os.path.join(HERE, "csrc", "aps_common.hpp"), os.path.join(HERE, "csrc", "tile_step.hpp"), os.path.join(HERE, "csrc", "tile_dense.hpp"), os.path.join(HERE, "csrc", "tile_loop.hpp"), os.path.join(HERE, "csrc", "ntt_conv.hpp"),
         os.path.join(ROOT, "include", "gillespie.h")]
 LIB = os.path.join(HERE, "libaps_hip.so")
 ARCH = "gfx950"

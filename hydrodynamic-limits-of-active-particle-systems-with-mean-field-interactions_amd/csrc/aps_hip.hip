@@ -1183,6 +1183,7 @@ __global__ __launch_bounds__(256) void observe_scalars(const ScalarArgs a) {
 }
 
 #include "tile_step.hpp"
+#include "tile_dense.hpp"
 #include "tile_loop.hpp"
 #include "ntt_conv.hpp"
 
@@ -1999,6 +2000,17 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
     int rc = field_only ? APS_OK : prof_mark(h, KIND_TILE_STEP);
     if (rc) return rc;
     TileArgs a = tile_args(h, field_only);
+    if (h->ntt_on) {                                            // the convolution keeps {W, S} complete: the step without any sweep (tile_dense.hpp)
+        if (field_only) return fail(h, APS_ERR_STATE, "tiles, convolution: no deposits are ever pending");
+        a.tile_lo = 0;
+        const dim3 grid((unsigned)td_tiles(h->p.L), (unsigned)h->E), block(FU_THREADS);
+        const void *fn = h->p.K == 1 ? reinterpret_cast<const void *>(&tile_dense<true>) : reinterpret_cast<const void *>(&tile_dense<false>);
+        void *args[] = {(void *)&a};
+        if (h->profiling && h->prof_dispatch) HIP_TRY(h, hipExtLaunchKernel(fn, grid, block, args, td_lds_bytes(h->p.K), h->stream, h->k_start, h->k_stop, 0));
+        else HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, td_lds_bytes(h->p.K), h->stream));
+        h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true;
+        return APS_OK;
+    }
     int t0 = h->ts_lo, t1 = h->ts_hi;
     if (h->world > 1) {
         // the ghost tiles whose inputs are still complete `halo_age` steps after the exchange; a flush also covers the
@@ -2009,7 +2021,7 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
         t1 = h->p.periodic ? t1 + g : std::min(h->ts_ntile, t1 + g);
     }
     const void *fn = ts_kernel(h->p.periodic != 0, h->ts_table_in_lds, h->ts_RS, h->p.K == 1, h->f32);
-    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h), h->ntt_on).total;
+    const size_t lds = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total;
     const void *table_ptr = h->f32 ? (const void *)h->d_table_i : (const void *)h->d_table;
     void *args[] = {(void *)&a, (void *)&table_ptr};
     // a range that wraps around the torus (flush of a sharded periodic handle) is launched in pieces
@@ -2078,7 +2090,7 @@ int ntt_setup(aps_handle *h) {
     if (!(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;   // one wall image per deposit at most (tile_step's mirror_ok)
     int m = 14;
     while (((int64_t)1 << m) < (int64_t)L + 2 * Rt) ++m;
-    if (m > 21) return APS_OK;
+    if (m > 21 || td_lds_bytes(h->p.K) > 64 * 1024) return APS_OK;
     // exactness: |dW|, |dS| <= 2 K sum_d w(d) must stay below P / 2
     double wsum = 0.0;
     for (int t = 0; t < h->tlen; ++t) wsum += std::ldexp(h->table[(size_t)t], h->q) * (t ? 2.0 : 1.0);

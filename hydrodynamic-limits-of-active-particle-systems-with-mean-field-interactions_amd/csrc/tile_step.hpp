@@ -31,7 +31,7 @@ struct TileRare { double *exit_log; unsigned *n_exit; uint32_t *src; const uint3
 
 struct TileArgs {
     int L, K, tlen, own, ntile, dcap, par, tile_lo, field_only, field_mode, ens_base, E;
-    int dense_rt, dense_m;                             // dense != NULL: the deposits of the step go into the coefficient signals of the
+    int dense_rt, dense_m;                             // tile_dense.hpp only: the deposits of the step go into the coefficient signals of the
     int *dense;                                        // convolution (ntt_conv.hpp) [E][2][2^dense_m], index = site + dense_rt, instead of lists
     uint32_t seed_lo, seed_hi;                         // Philox key
     const Model *model;                                // device copy of the rate parameters (read by the proposal phase)
@@ -56,8 +56,7 @@ __host__ __device__ inline int ts_win_entries(int RS, int own) { return ((TS_WH 
 constexpr int TS_SHCAP = 320;              // windowed sweep: capacity of a shared class list (a round adds at most 256 entries); per side: half
 constexpr int TS_SEG = 128;                // entries per deposit segment of a wave (four segments: P, M, F, image)
 struct TsLds { size_t seg, cells, props, occ, misc, plist, tab, field, total; int Q; bool cells_in_regs; };
-// no_table: the field arrives complete (deposits go to the convolution of ntt_conv.hpp): neither table nor windows in LDS
-__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K, int wbytes = 8, bool no_table = false) {
+__host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, int own, int K, int wbytes = 8) {
     TsLds l;
     const size_t TS = 64 * (size_t)RS;
     const int ncell = (int)(TS + 2) * K;
@@ -70,7 +69,7 @@ __host__ __device__ inline TsLds ts_lds_layout(int tlen, bool tab_lds, int RS, i
     l.misc = l.occ + (TS + 2 + 7) / 8 * 8;
     l.plist = l.misc + 128;
     l.tab = (l.plist + (l.cells_in_regs ? TS * (size_t)K * 8 : 0) + 15) / 16 * 16;
-    const size_t table = no_table ? 0 : (tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes);
+    const size_t table = tab_lds ? (size_t)ts_table_chunks(tlen, RS, own, wbytes) * 1024 : (size_t)2 * ts_win_entries(RS, own) * wbytes;
     const size_t red = (size_t)FU_WAVES * TS * 2 * wbytes;
     l.field = l.tab + red;                                      // fresh {W, S} of the frame sites, behind the partial sums
     const size_t after = red + TS * sizeof(double2);
@@ -260,7 +259,7 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
     constexpr int NR = K1 ? ((TS + 2 + FU_WAVES - 1) / FU_WAVES + 63) / 64 : TS_CREG;   // register rounds of the wave's cell chunk
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K, OWN = a.own;
-    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K, WB, a.dense != nullptr);
+    const TsLds lay = ts_lds_layout(a.tlen, TAB_LDS, RS, OWN, K, WB);
     char *lds_c = reinterpret_cast<char *>(lds);
     uint32_t *seg_all = reinterpret_cast<uint32_t *>(lds_c + lay.seg);
     uint32_t *cellL = reinterpret_cast<uint32_t *>(lds_c + lay.cells);       // [(TS + 2) K]: frame positions -1 .. TS
@@ -301,7 +300,7 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
     // The table goes straight into LDS (LDS-direct loads, 1 KB per wave instruction, no registers); the global copy is
     // followed by zeros, so the padded tail comes along.  Written as inline assembly like the windows below (the compiler
     // would put an s_waitcnt vmcnt(0) in front of every later LDS read); the wait in front of the barrier orders it.
-    if (TAB_LDS && !a.dense) {
+    if (TAB_LDS) {
         const int nchunk = ts_table_chunks(a.tlen, RS, OWN, WB);
         const char *srct = reinterpret_cast<const char *>(table_g) + lane * 16;
         for (int c = wave; c < nchunk; c += FU_WAVES) {
@@ -345,7 +344,7 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
     }
     // buckets (= tiles) whose deposits can reach the frame: one run of nbk buckets from b0 that may wrap around the torus
     int b0 = 0, nbk = 0;
-    if (a.field_mode && !a.dense) {                            // (dense: ws_in already holds the field of the current cells)
+    if (a.field_mode) {
         if (BC == 0) {
             b0 = max(0, x0c - Rt - 1) / OWN;
             nbk = min(L - 1, x1c + Rt + 1) / OWN - b0 + 1;
@@ -429,7 +428,7 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
     }
     TSTAMP(f_stage)
     // ---------------------------------------------------------------- 1  deposits of the previous step -> W, S of the frame
-    const bool windowed = !TAB_LDS && BC == 0 && !wall && !a.dense;
+    const bool windowed = !TAB_LDS && BC == 0 && !wall;
     const uint32_t tb = TAB_LDS ? tbase : 0u;                  // table in global memory: byte offsets from its start
     const uint32_t win_lds = tbase;
     const int WIN = ts_win_entries(RS, OWN);
@@ -666,8 +665,7 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
             for (int w = 0; w < FU_WAVES; ++w) { const WS pth = red[(size_t)w * TS + xi]; f.x += pth.x; f.y += pth.y; }
             // S / W does not care about the unit (2^-q in the integer field): the proposals read doubles either way
             fieldL[xi] = a.field_mode ? make_double2((double)f.x, (double)f.y) : make_double2((double)misc[5], (double)misc[4]);
-            // (dense: {W, S} live in ONE buffer that the convolution updates in place -- nothing to carry over to the other parity)
-            if (a.field_mode && !a.dense && xi >= 2 && xi < 2 + own_n) reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
+            if (a.field_mode && xi >= 2 && xi < 2 + own_n) reinterpret_cast<WS *>(a.ws_out)[(size_t)e * L + (unsigned)frame_site(xi)] = f;
         }
     }
     if (a.field_only) return;                                  // flush of the pending deposits only (observation)
@@ -720,24 +718,10 @@ __global__ TS_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_step(const Tile
     uint32_t *dep_o = a.dep_out + ((size_t)e * a.ntile + tile) * a.dcap;
     uint32_t *cell_o = a.cell_out + (size_t)e * L * K;
     int my_spin = 0, my_live = 0;
-    // the deposits of one event: into the tile's list, or (dense) into the coefficient signals of the convolution, wall images included
-    auto emit_deposits = [&](const int nd, const uint32_t d0, const uint32_t d1) {
+    auto emit_deposits = [&](const int nd, const uint32_t d0, const uint32_t d1) {          // the deposits of one event: into the tile's list
         if (!nd || !a.field_mode) return;
-        if (a.dense) {
-            int *cw_sig = a.dense + ((size_t)e << (a.dense_m + 1)), *cs_sig = cw_sig + ((size_t)1 << a.dense_m);
-            for (int u = 0; u < nd; ++u) {
-                const uint32_t d = u ? d1 : d0;
-                const int ds_ = (int)(d & POS_MASK), cw = (int)((d >> 27) & 3u) - 1, cs = (int)(d >> 29) - 2;
-                const int at = ds_ + a.dense_rt;
-                if (cw) atomicAdd(cw_sig + at, cw);
-                atomicAdd(cs_sig + at, cs);
-                const int img = ds_ < a.dense_rt ? a.dense_rt - 1 - ds_ : (ds_ >= L - a.dense_rt ? 2 * L - 1 - ds_ + a.dense_rt : -1);
-                if (img >= 0) { if (cw) atomicAdd(cw_sig + img, cw); atomicAdd(cs_sig + img, cs); }
-            }
-        } else {
-            const int kd = atomicAdd(&misc[0], nd);
-            if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
-        }
+        const int kd = atomicAdd(&misc[0], nd);
+        if (kd + nd <= a.dcap) { dep_o[kd] = d0; if (nd == 2) dep_o[kd + 1] = d1; }
     };
     // the event of the particle `c` on site s (frame position xi): returns whether it is still on the site afterwards (c updated);
     // hop_granted: the exclusion rule let its hop to frame position j through
