@@ -36,19 +36,21 @@ inline uint32_t ntt_powmod(uint32_t b, unsigned long long e) {
     return r;
 }
 
-// Residues travel LAZILY: integers in [0, 2 P) (2 P < 2^32, so a uint32 holds them), as uint32 in global memory and as doubles
-// in LDS and registers.  Quotients are estimated by floor(x / P - 2^-10): never above the true quotient, at most one below it
-// for every product that occurs here (operands below 2^36 and 2^32: the estimate's error is far below 2^-10), so a remainder
-// lies in [0, 2 P) without any correction step.
+// Residues travel LAZILY: integers in [0, 2 P) (2 P < 2^32, so a uint32 holds them) as uint32 in global memory; in registers and
+// LDS doubles of EITHER sign whose magnitude the butterflies let grow (a level doubles it at most: below 2^8 * 2 P < 2^39 after
+// the seven levels of a 128-point transform) until the next product brings them back to [0, 2 P).  Quotients are estimated by
+// floor(x / P - 2^-10): never above the true quotient (floor: also for negative x), at most one below it for every product that
+// occurs here (|a| < 2^39, b < 2^32: quotient below 2^40.1, three roundings of 2^-53 relative + the dropped low part l / P <
+// 2^-14 -> error below 2^-11 < 2^-10), so a remainder lies in [0, 2 P) without any correction step.
 constexpr double NTT_BIAS = 0.0009765625;                        // 2^-10
-// a * b mod P, lazy: a < 2^36, b < 2^32 -> [0, 2 P).  Exact: a b = h + l with l from fma; h - q P is a small integer (fma again).
+// a * b mod P, lazy: |a| < 2^39, 0 <= b < 2^32 -> [0, 2 P).  Exact: a b = h + l with l from fma; h - q P is a small integer (fma again).
 __device__ __forceinline__ double ntt_mul(double a, double b) {
     const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
     const double h = a * b, l = fma(a, b, -h);
     const double q = floor(fma(h, Pinv, -NTT_BIAS));
     return fma(-q, Pd, h) + l;
 }
-__device__ __forceinline__ double ntt_red(double v) {             // v an integer in [0, 2^40) -> [0, 2 P), congruent
+__device__ __forceinline__ double ntt_red(double v) {             // v an integer, |v| < 2^40 -> [0, 2 P), congruent
     const double q = floor(fma(v, 1.0 / (double)NTT_P, -NTT_BIAS));
     return fma(-q, (double)NTT_P, v);
 }
@@ -71,8 +73,7 @@ struct NttPlan {
 // for the rare n = j = 0: a branch per butterfly would cost more than the product)
 template <int B, bool N0>
 __device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double *__restrict__ wtab, const int n, const int lo_shift, const int s0) {
-    // values entering level s are below CP[s] (lazy residues below 2 P at first; a sum doubles the bound, a product is below 2 P)
-    constexpr double CP[5] = {2.0 * NTT_P, 4.0 * NTT_P, 8.0 * NTT_P, 16.0 * NTT_P, 32.0 * NTT_P};
+    // a level at most doubles the magnitude of its values (sums and differences; a product is back in [0, 2 P))
 #pragma unroll
     for (int s = 0; s < B; ++s) {
         constexpr int NV = 1 << B;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double
             const int j = pr & (ht - 1), u = ((pr - j) << 1) + j, v = u + ht;
             const double xa = x[u], xb = x[v];
             x[u] = xa + xb;
-            const double d = (xa - xb) + CP[s];                            // positive: both below CP[s]
+            const double d = xa - xb;                                      // either sign: the quotient estimate of ntt_mul floors
             const int e = (n + (j << lo_shift)) << (s0 + s);               // < 64
             if (N0 && j == 0) x[v] = d; else x[v] = ntt_mul(d, wtab[e]);
         }
@@ -102,7 +103,7 @@ __device__ __forceinline__ void ntt_lds_transform(double *buf, const int lg_nc, 
         for (int tt = 0; tt < (1 << AH); ++tt) x[tt] = buf[(n + (tt << AL)) * ld + c];
         ntt_reg_levels<AH, false>(x, wtab, n, AL, 0);
 #pragma unroll
-        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = ntt_red(x[tt]);
+        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = AL > 0 ? x[tt] : ntt_red(x[tt]);   // (reduced by the last pass)
     }
     __syncthreads();
     if constexpr (AL > 0) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
             if (!INV && init_or_final) {                         // deposit coefficients (small signed integers), cleared for the next step
                 const int x0 = (int)raw[u];
                 if (x0) c0[base + (size_t)r * stride + c] = 0;
-                v0 = x0 < 0 ? (double)NTT_P + (double)x0 : (double)x0;
+                v0 = (double)x0;
             } else v0 = (double)raw[u];
             if (AXIS == 1 && !INV) v0 = ntt_mul(v0, (double)twv[u]);
             buf[r * ld + c] = v0;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
 // Register hand-overs: the load is already the first pass of the first sweep (thread t holds words t + 1024 tt = rows n + 8 tt of
 // column t & 127), the second pass of the forward i0 sweep of two neighbouring groups is the first pass of the inverse one (16
 // adjacent slots), the last pass stores straight to memory: 7 LDS reads and 6 writes of the tile in all.
+// No reduction anywhere: every run of seven butterfly levels ends in a product (twiddle or spectrum), which takes |a| < 2^39.
 // Twiddles w^(+-e): along a thread's 16 rows the exponents are an arithmetic progression -- two table look-ups and 18 products.
 constexpr int NTT_MID_THREADS = 1024;
 constexpr int NTT_MID_LD = 129;
@@ -338,11 +340,14 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul((double)raw[tt], (double)t1f[(size_t)(n + 8 * tt) * k2]);
     }
+    uint32_t wv[16];                                            // the table's spectrum at this thread's slots of the product: asked for now
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wv[j] = wslab[(16 * n + j) * 128 + c];
     __syncthreads();
     // forward over i1, pass 1 (rows n + 8 tt of column c) -- in the registers of the load
     ntt_reg_levels<4, false>(x, wf, n, 3, 0);
 #pragma unroll
-    for (int tt = 0; tt < 16; ++tt) buf[(n + 8 * tt) * LD + c] = ntt_red(x[tt]);
+    for (int tt = 0; tt < 16; ++tt) buf[(n + 8 * tt) * LD + c] = x[tt];
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {                             // pass 2: rows 8 u + v
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         for (int v = 0; v < 8; ++v) y[v] = buf[(8 * u + v) * LD + c];
         ntt_reg_levels<3, true>(y, wf, 0, 0, 4);
 #pragma unroll
-        for (int v = 0; v < 8; ++v) buf[(8 * u + v) * LD + c] = ntt_red(y[v]);
+        for (int v = 0; v < 8; ++v) buf[(8 * u + v) * LD + c] = y[v];
     }
     __syncthreads();
     {   // forward over i0 of the i1-slot c (k1 = brev(c)), pass 1: i0 = n + 8 tt, twiddle 2 = w^(i0 q), q = k2 + R2 k1
@@ -363,13 +368,10 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul(buf[c * LD + n + 8 * tt], tw[tt]);
         ntt_reg_levels<4, false>(x, wf, n, 3, 0);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) buf[c * LD + n + 8 * tt] = ntt_red(x[tt]);
+        for (int tt = 0; tt < 16; ++tt) buf[c * LD + n + 8 * tt] = x[tt];
     }
     __syncthreads();
     {   // pass 2 of the groups u = 2 n, 2 n + 1 (slots 16 n .. 16 n + 15), the product, pass 1 of the inverse sweep (its n' = brev3(n))
-        uint32_t wv[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) wv[j] = wslab[(16 * n + j) * 128 + c];
         double y0[8], y1[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) { y0[v] = buf[c * LD + 16 * n + v]; y1[v] = buf[c * LD + 16 * n + 8 + v]; }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         for (int tt = 0; tt < 16; ++tt) x[tt] = y[ntt_brev4(tt)];                 // logical row n' + 8 tt sits in slot 16 n + brev4(tt)
         ntt_reg_levels<4, false>(x, wi, ntt_brev3(n), 3, 0);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) buf[c * LD + 16 * n + ntt_brev4(tt)] = ntt_red(x[tt]);
+        for (int tt = 0; tt < 16; ++tt) buf[c * LD + 16 * n + ntt_brev4(tt)] = x[tt];
     }
     __syncthreads();
 #pragma unroll
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         for (int v = 0; v < 8; ++v) y[v] = buf[c * LD + 16 * ntt_brev3(v) + ub];
         ntt_reg_levels<3, true>(y, wi, 0, 0, 4);
 #pragma unroll
-        for (int v = 0; v < 8; ++v) buf[c * LD + 16 * ntt_brev3(v) + ub] = ntt_red(y[v]);
+        for (int v = 0; v < 8; ++v) buf[c * LD + 16 * ntt_brev3(v) + ub] = y[v];
     }
     __syncthreads();
     {   // inverse over i1 at i0 = c, pass 1: logical rows k1 = n + 8 tt in slots 16 brev3(n) + brev4(tt); twiddle 2^-1 = w^(-c (k2 + R2 k1))
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul(buf[(nb + ntt_brev4(tt)) * LD + c], tw[tt]);
         ntt_reg_levels<4, false>(x, wi, n, 3, 0);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) buf[(nb + ntt_brev4(tt)) * LD + c] = ntt_red(x[tt]);
+        for (int tt = 0; tt < 16; ++tt) buf[(nb + ntt_brev4(tt)) * LD + c] = x[tt];
     }
     __syncthreads();
 #pragma unroll

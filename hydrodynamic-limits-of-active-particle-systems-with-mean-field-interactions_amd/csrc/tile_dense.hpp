@@ -13,7 +13,10 @@
 // The frames are this kernel's own (the cells are indexed by site, not by tile): TD_OWN owned sites, two halo sites either side.
 #pragma once
 
-constexpr int TD_SITES = 512, TD_OWN = TD_SITES - 4;
+#ifndef APS_TD_SITES
+#define APS_TD_SITES 512                   /* tuning builds: sites per frame */
+#endif
+constexpr int TD_SITES = APS_TD_SITES, TD_OWN = TD_SITES - 4;
 __host__ __device__ inline size_t td_lds_cells(int K) { return ((size_t)(TD_SITES + 2) * K * 4 + 7) / 8 * 8; }
 __host__ __device__ inline size_t td_lds_bytes(int K) { return td_lds_cells(K) + (size_t)TD_SITES * K * 8 + ((size_t)TD_SITES * K + 15) / 16 * 16 + 16; }
 inline int td_tiles(int L) { return (L + TD_OWN - 1) / TD_OWN; }
