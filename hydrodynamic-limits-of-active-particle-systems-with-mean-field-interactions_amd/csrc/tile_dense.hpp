@@ -14,7 +14,7 @@
 #pragma once
 
 #ifndef APS_TD_SITES
-#define APS_TD_SITES 512                   /* tuning builds: sites per frame */
+#define APS_TD_SITES 1024                  /* tuning builds: sites per frame */
 #endif
 constexpr int TD_SITES = APS_TD_SITES, TD_OWN = TD_SITES - 4;
 __host__ __device__ inline size_t td_lds_cells(int K) { return ((size_t)(TD_SITES + 2) * K * 4 + 7) / 8 * 8; }
