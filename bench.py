@@ -593,6 +593,8 @@ def main():
             # around the launch instead, which read ~2 us more per kernel (the event packets' own cost).
             kern = {k: v[0] / v[1] * 1e-3 for k, v in prof.items() if v[1]}
             ntt = h.ntt_info()
+            if ntt["on"] and "tile_step" in kern:      # convolution handles step by tile_dense (csrc/tile_dense.hpp): no sweep, no lists
+                kern["tile_dense"] = kern.pop("tile_step")
             if ntt["on"] and ntt["prof_launches"]:     # the field update as an exact convolution (csrc/ntt_conv.hpp): three (five) launches per step
                 kern["ntt_conv"] = ntt["prof_ms"] / ntt["prof_launches"] * 1e-3
             bracketed = os.environ.get("APS_PROF_BRACKET") is not None
@@ -606,6 +608,8 @@ def main():
                                     for x, y in zip(before, [h.get_state(ensemble=e) for e in range(n_ens)])))
                 del before
             algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32")), changed) for k in kern}
+            if "tile_dense" in algo:                   # cell words read and written, {W, S} (two int32) at the particles' sites; the coefficient atomics left out
+                algo["tile_dense"] = 8.0 * w["K"] * L_all + 8.0 * N_all
             launches_per_step = {k: 1 for k in kern}
             if "ntt_conv" in kern:
                 # per launch: both signals of 2^m residues read and written (4 B each); per step on top: the deposit signals read

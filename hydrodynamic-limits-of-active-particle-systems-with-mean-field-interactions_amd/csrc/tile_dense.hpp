@@ -48,19 +48,39 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
     __syncthreads();
     // ---------------------------------------------------------------- 0  cells, particle list
     const int ncell = (TD_SITES + 2) * K;
-    for (int c0 = 0; c0 < ncell; c0 += FU_THREADS) {
-        const int c = c0 + t;
-        const int pos = K1 ? c - 1 : c / K - 1, k = K1 ? 0 : c - (pos + 1) * K;
-        const int s = c < ncell ? frame_site(pos) : -1;
-        uint32_t v = cell_e[(unsigned)max(s, 0) * (unsigned)K + (unsigned)k];
-        if (s < 0) v = CELL_EMPTY;
-        if (c < ncell) cellL[c] = v;
+    auto append = [&](const uint32_t v, const int pos, const int k) {   // an occupied cell of the valid frame -> the particle list
         const bool occ = v != CELL_EMPTY && pos >= 0 && pos < nfr;
         const unsigned long long mm = __ballot(occ);
         int base = 0;
         if (lane == 0 && mm) base = atomicAdd(&misc[0], __popcll(mm));
         base = __builtin_amdgcn_readfirstlane(base);
         if (occ) plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = make_uint2((uint32_t)pos | ((uint32_t)k << 16), v);
+    };
+    if constexpr (K1) {                                        // every cell word of the frame requested before the first is looked at
+        constexpr int NR = (TD_SITES + 2 + FU_THREADS - 1) / FU_THREADS;
+        uint32_t creg[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int c = u * FU_THREADS + t, s = c < ncell ? frame_site(c - 1) : -1;
+            creg[u] = cell_e[(unsigned)max(s, 0)];
+            if (s < 0) creg[u] = CELL_EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int c = u * FU_THREADS + t;
+            if (c < ncell) cellL[c] = creg[u];
+            append(creg[u], c - 1, 0);
+        }
+    } else {
+        for (int c0 = 0; c0 < ncell; c0 += FU_THREADS) {
+            const int c = c0 + t;
+            const int pos = c / K - 1, k = c - (pos + 1) * K;
+            const int s = c < ncell ? frame_site(pos) : -1;
+            uint32_t v = cell_e[(unsigned)max(s, 0) * (unsigned)K + (unsigned)k];
+            if (s < 0) v = CELL_EMPTY;
+            if (c < ncell) cellL[c] = v;
+            append(v, pos, k);
+        }
     }
     __syncthreads();
     const int n_part = misc[0];
@@ -73,7 +93,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
     // ---------------------------------------------------------------- 1  proposals, a lane per particle
     {
         const Model M = *a.model;                              // uniform address: scalar loads
-        for (int j = t; j < n_part; j += FU_THREADS) {
+        for (int j = t; j < n_part; j += FU_THREADS) {         // (two particles a lane and round, both requests out first: slower -- 81 VGPRs, five waves)
             const uint2 pc = plist[j];
             const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16), s = x0 + pos;
             const int2 f = ws_e[(unsigned)s];

@@ -4,7 +4,7 @@ import collections, json, re, sqlite3, sys
 
 
 def short(name):
-    m = re.search(r"(ntt_strided<[12], (?:true|false)|ntt_contig|tile_loop|tile_step|pair_accumulate|plan_tiles|propose_lattice|field_update|propose|apply|claim|field_sites|copy16|cells_to_slots|derive_slots|tile_parts)", name)
+    m = re.search(r"(ntt_strided<[12], (?:true|false)|ntt_contig|ntt_mid|tile_dense|tile_loop|tile_step|pair_accumulate|plan_tiles|propose_lattice|field_update|propose|apply|claim|field_sites|copy16|cells_to_slots|derive_slots|tile_parts)", name)
     return m.group(1) if m else name.split("(")[0][:40]
 
 
