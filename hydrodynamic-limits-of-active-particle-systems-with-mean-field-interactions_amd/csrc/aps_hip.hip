@@ -2090,7 +2090,12 @@ int ntt_setup(aps_handle *h) {
     if (!(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;   // one wall image per deposit at most (tile_step's mirror_ok)
     int m = 14;
     while (((int64_t)1 << m) < (int64_t)L + 2 * Rt) ++m;
-    if (m > 21 || td_lds_bytes(h->p.K) > 64 * 1024) return APS_OK;
+    if (m > 21 || td_lds_bytes(h->p.K) > 160 * 1024) return APS_OK;
+    if (td_lds_bytes(h->p.K) > 48 * 1024 &&                     // frames of tile_dense with many cells per site
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_lds_bytes(h->p.K)) != hipSuccess) {
+        (void)hipGetLastError();
+        return APS_OK;
+    }
     // exactness: |dW|, |dS| <= 2 K sum_d w(d) must stay below P / 2
     double wsum = 0.0;
     for (int t = 0; t < h->tlen; ++t) wsum += std::ldexp(h->table[(size_t)t], h->q) * (t ? 2.0 : 1.0);

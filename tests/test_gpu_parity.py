@@ -1051,6 +1051,34 @@ def test_fp32_convolution_with_ensembles_anchors_and_exits(capi):
         h.close()
 
 
+def test_fp32_convolution_with_six_cells_per_site(capi):
+    """csrc/tile_dense.hpp with K = 6: a frame's cells, particle list and proposals (80 KB) need the enlarged LDS limit; the general
+    exclusion rule (rank among the proposers of a site against its free capacity) on crowded sites, bit for bit against the oracle."""
+    par = params(L=30000, K=6, sigma=0.01, rate_diffusion=4.0)
+    rng = np.random.default_rng(21)
+    N = 60000
+    pos, spin = random_state(rng, par.L, N, par.K)
+    orc = so.SyncOracle(par, dt=0.04, seed=3, sum_bits=29)
+    orc.set_state(pos, spin)
+    os.environ["APS_NTT"] = "1"
+    try:
+        h = make_handle(capi, par, N, dt=0.04, seed=3, method="tiles", fp32=True)
+    finally:
+        del os.environ["APS_NTT"]
+    try:
+        assert h.ntt_info()["on"] and h.ntt_info()["launches"] == 3
+        h.set_state(pos, spin)
+        for n in (1, 12):
+            h.step(n)
+            orc.run(n)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin), n
+            check_lattice(h, orc)
+        assert (p != pos).mean() > 0.3
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("update", ["convolution", "sweep"])
 def test_fp32_config5_scale_against_oracle_windows(capi, update):
     """BASELINE config 5 as it is worded (N = 1e6, float32): the int32 field after 200 steps against the oracle's stencil
