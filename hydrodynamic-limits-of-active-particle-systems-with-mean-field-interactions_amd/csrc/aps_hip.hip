@@ -2195,7 +2195,6 @@ int loop_prepare(aps_handle *h) {
     if (h->ntt_on) return no("field updated by the exact convolution");
     if (!h->ts_table_in_lds) return no("weight table beyond LDS");
     if (!h->model.field_mode) return no("global mean field");
-    if (h->model.immobilize && h->model.k_exit > 0.0) return no("particles can leave the system");
     if (3 * h->p.K > 32) return no("site capacity above 10");
     if (h->p.L - (int64_t)(h->ts_ntile - 1) * h->ts_own < 3) return no("last tile shorter than three sites");
 #ifdef APS_STAMPS
@@ -3071,6 +3070,14 @@ int aps_step(aps_handle *h, int64_t nsteps) {
                 // stay intact for the fallback; after an even number of steps that set holds the state of the SAME parity:
                 // the two sets trade places (captured graphs are kept per `flip`)
                 const int64_t n = std::min<int64_t>(nsteps - s, (int64_t)1 << 30);
+                // particles that can leave: a call that is given up has already logged exits of steps that will be repeated --
+                // the counts of before put the log back (the repeated steps write the same rows and the same dead marks again)
+                const bool exits = h->model.k_exit > 0.0;
+                std::vector<unsigned> n_exit_before;
+                if (exits) {
+                    n_exit_before.resize((size_t)h->E);
+                    HIP_TRY(h, hipMemcpyAsync(n_exit_before.data(), h->d_nexit, (size_t)h->E * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+                }
                 if ((rc = launch_tile_loop(h, n))) return rc;
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
 #ifdef APS_LOOP_DEBUG
@@ -3087,6 +3094,7 @@ int aps_step(aps_handle *h, int64_t nsteps) {
                     // a tile that finished all n iterations before the call was given up has written the step word of the
                     // final parity -- for an even n that is the word the first repeated step reads: set the pair again
                     if ((rc = upload_stepw(h))) return rc;
+                    if (exits) HIP_TRY(h, hipMemcpy(h->d_nexit, n_exit_before.data(), (size_t)h->E * sizeof(unsigned), hipMemcpyHostToDevice));
                 } else {
                     h->step += n; s += n; h->last_loop_steps = n;
                     h->slots_dirty = true; h->field_pending = true; h->ws_view_stale = true;

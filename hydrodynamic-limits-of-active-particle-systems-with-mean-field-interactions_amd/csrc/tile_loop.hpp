@@ -539,6 +539,16 @@ __global__ __launch_bounds__(FU_THREADS, TL_MIN_WAVES) void tile_loop(const Loop
         };
         auto cap_at = [&](int j) -> int { const int c = K - (int)occL[j + 1]; return c < 1 ? 1 : (c > 32 ? 32 : c); };
         auto put_deposit = [&](int kd, uint32_t d) { if (last) dep_o[kd] = d; else tl_store_granule(rec_out + kd, tag_out, d); };
+        auto log_exit = [&](const uint32_t c, const int s) {   // a particle leaves the system (ref :307-312, :427-446): exit log, its slot marked dead
+            const TileRare R = *a.rare;
+            const unsigned kx = atomicAdd(&R.n_exit[e], 1u);
+            if ((int)kx < R.exit_cap) {
+                double *row = R.exit_log + ((size_t)e * R.exit_cap + kx) * 3;
+                row[0] = (double)step; row[1] = (double)s; row[2] = (double)(c & CELL_ID);
+            }
+            R.src[(size_t)e * R.Npad + R.slot_of[(size_t)e * R.N + (c & CELL_ID)]] =
+                (uint32_t)s | DEAD_BIT | ((c & CELL_PLUS) ? SPIN_BIT : 0u) | ((c & CELL_BOUND) ? BOUND_BIT : 0u);
+        };
         uint32_t newc[NOLD];                                   // K = 1: the owned sites' cells after this step
         int newn[NOLD];                                        // particles on the site after this step
 #pragma unroll
@@ -575,6 +585,7 @@ __global__ __launch_bounds__(FU_THREADS, TL_MIN_WAVES) void tile_loop(const Loop
                     } else if (p0 == EV_BIND) c |= CELL_BOUND;
                     else if (p0 == EV_UNBIND) c &= ~CELL_BOUND;
                     else if (p0 == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
+                    else if (p0 == EV_EXIT) { stays = false; log_exit(c, s); d0 = deposit(s, -1, -sgn); nd = 1; }
                     if (stays) { newc[r] = c; newn[r] = 1; }
                     if (nd) {
                         const int kd = atomicAdd(dcount, nd);
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(FU_THREADS, TL_MIN_WAVES) void tile_loop(const Loop
                 } else if (ev == EV_BIND) c |= CELL_BOUND;
                 else if (ev == EV_UNBIND) c &= ~CELL_BOUND;
                 else if (ev == EV_FLIP) { c ^= CELL_PLUS; d0 = deposit(s, 0, -2 * sgn); nd = 1; }
-                // (EV_EXIT cannot be drawn: the host only takes this path when no particle can leave)
+                else if (ev == EV_EXIT) { stays = false; log_exit(c, s); d0 = deposit(s, -1, -sgn); nd = 1; }
                 if (stays) emit(c);
                 if (nd) {
                     const int kd = atomicAdd(dcount, nd);

@@ -266,7 +266,7 @@ int aps_ntt_launches(aps_handle *h);
  * sits in LDS (else: windows of it, tile_step's windowed sweep). */
 int aps_tiles_info(aps_handle *h, int32_t *frame_sites, int32_t *owned_sites, int32_t *n_tiles, int32_t *table_in_lds);
 
-/* Resident loop (TILES, one rank, weight table in LDS, local field, no exits, the whole grid of tiles resident on the device
+/* Resident loop (TILES, one rank, weight table in LDS, local field, the whole grid of tiles resident on the device
  * at once -- BASELINE config 2): aps_step then runs its steps inside ONE launch; every tile keeps its state on chip and
  * exchanges only deposit lists and boundary cells with its neighbours between two steps.  Same bits as one launch per step
  * (replaces the loop of ParticleSystem.run, PARTICLE_solver_CLASS.py:511-516, like aps_step itself).  on = 0 keeps a handle

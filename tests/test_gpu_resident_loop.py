@@ -41,6 +41,11 @@ LOOP_CASES = [
     dict(tag="k2_periodic_wide", L=400, K=2, sigma=0.4, periodic=True, frac=0.5),
     dict(tag="anchors_bind_unbind", L=900, K=2, sigma=0.02, frac=0.5, anchor_positions=[0.3, 0.7], anchor_radius=0.08,
          k_on=3.0, k_off=1.0, k_exit=0.0),
+    # particles leave the system (ref :307-312, :427-446): exit log and dead marks written from inside the loop
+    dict(tag="anchors_exits", L=900, K=2, sigma=0.02, frac=0.5, anchor_positions=[0.3, 0.7], anchor_radius=0.08,
+         k_on=3.0, k_off=1.0, k_exit=1.5),
+    dict(tag="k3_anchors_exits_many_tiles", L=2500, K=3, sigma=0.01, frac=0.5, anchor_positions=[0.2, 0.5, 0.8], anchor_radius=0.05,
+         k_on=4.0, k_off=0.5, k_exit=2.0),
     dict(tag="dense_diffusive", L=1280, K=1, sigma=0.05, frac=0.9, rate_diffusion=6.0),
     dict(tag="ragged_last_tile", L=60 * 7 + 5, K=1, sigma=0.03, frac=0.5),
     dict(tag="single_tile_torus", L=50, K=2, sigma=0.1, periodic=True, frac=0.5),
@@ -81,6 +86,9 @@ def test_resident_loop_equals_oracle(capi, case, fp32):
         t, k = h.time()
         assert k == total
         assert not np.array_equal(h.get_state()[0], pos)
+        assert np.array_equal(h.exits(), orc.exits())
+        if case.get("k_exit", 0.0) > 0.0:
+            assert (orc.alive == 0).sum() > 10, tag
     finally:
         del os.environ["APS_LOOP_MIN"]
         h.close()
@@ -158,9 +166,8 @@ def test_resident_loop_ensembles(capi):
 
 
 def test_not_eligible_falls_back_silently(capi):
-    """Exits possible, a global mean field, or a last tile shorter than three sites: one launch per step, same results."""
-    for case, reason in [(dict(L=600, K=2, sigma=0.02, anchor_positions=[0.3, 0.7], anchor_radius=0.08, k_on=3.0, k_off=1.0, k_exit=2.0), "leave"),
-                         (dict(L=600, K=1, sigma=0.0), "global"), (dict(L=60 * 6 + 2, K=1, sigma=0.03), "three")]:
+    """A global mean field, or a last tile shorter than three sites: one launch per step, same results."""
+    for case, reason in [(dict(L=600, K=1, sigma=0.0), "global"), (dict(L=60 * 6 + 2, K=1, sigma=0.03), "three")]:
         par = params(**case)
         rng = np.random.default_rng(2)
         N = par.L * par.K // 2
@@ -218,6 +225,10 @@ def test_a_call_that_gives_up_is_repeated_the_ordinary_way(capi):
     dict(tag="k1_two_ensembles_even", L=70000, K=1, sigma=0.002, betas=[0.7, 1.9], frac=0.4, n=12, stall="200:4"),
     dict(tag="k2_odd", L=3000, K=2, sigma=0.01, betas=[1.1], frac=0.6, n=9, stall="3:2"),
     dict(tag="k1_tile_never_starts", L=3000, K=1, sigma=0.01, betas=[0.7], frac=0.5, n=10, stall="5:0"),
+    # particles leave while the call is under way: the far tiles have logged exits of steps that are then repeated -- the exit
+    # counts of before the call are put back, the repeated steps log the same rows again
+    dict(tag="k2_exits_logged_before_giving_up", L=3000, K=2, sigma=0.01, betas=[1.1], frac=0.6, n=30, stall="3:20",
+         extra=dict(anchor_positions=[0.3, 0.7], anchor_radius=0.08, k_on=4.0, k_off=0.5, k_exit=2.0)),
 ], ids=lambda c: c["tag"])
 def test_a_wait_that_runs_out_mid_loop(capi, case):
     """APS_LOOP_TEST_STALL=<tile>:<iteration>: that tile leaves at the top of that iteration without its record and without
@@ -225,7 +236,8 @@ def test_a_wait_that_runs_out_mid_loop(capi, case):
     are iterations ahead or already done; everyone leaves, aps_step repeats the call with one launch per step from the intact
     inputs: same bits as the oracle after the call and after 20 further steps (the device step words included: the random
     numbers of the repeated steps are those of the right step indices)."""
-    par0 = params(L=case["L"], K=case["K"], sigma=case["sigma"])
+    extra = case.get("extra", {})
+    par0 = params(L=case["L"], K=case["K"], sigma=case["sigma"], **extra)
     betas = case["betas"]
     rng = np.random.default_rng(21)
     N = max(1, int(case["frac"] * par0.L * par0.K))
@@ -233,7 +245,7 @@ def test_a_wait_that_runs_out_mid_loop(capi, case):
     dt, seed = 0.04, 31
     orcs = []
     for e, b in enumerate(betas):
-        orc = so.SyncOracle(params(L=case["L"], K=case["K"], sigma=case["sigma"], beta=b), dt=dt, seed=seed, ensemble=e)
+        orc = so.SyncOracle(params(L=case["L"], K=case["K"], sigma=case["sigma"], beta=b, **extra), dt=dt, seed=seed, ensemble=e)
         orc.set_state(*states[e])
         orcs.append(orc)
     h = make_handle(capi, par0, N, dt=dt, seed=seed, method="tiles", beta=betas)
@@ -246,6 +258,7 @@ def test_a_wait_that_runs_out_mid_loop(capi, case):
             for e, orc in enumerate(orcs):
                 got = h.get_state(ensemble=e)
                 assert np.array_equal(got[0], orc.pos) and np.array_equal(got[1], orc.spin) and np.array_equal(got[2], orc.bound), (tag, e)
+                assert np.array_equal(got[3], orc.alive) and np.array_equal(h.exits(ensemble=e), orc.exits()), (tag, e)
                 check_lattice(h, orc, ensemble=e)
 
         h.step(5)                                            # the loop works on this handle
@@ -269,6 +282,8 @@ def test_a_wait_that_runs_out_mid_loop(capi, case):
             orc.run(20)
         assert h.loop_info()[:2] == (0, -1)
         same("20 steps later")
+        if extra:
+            assert sum(int((orc.alive == 0).sum()) for orc in orcs) > 10
     finally:
         del os.environ["APS_LOOP_MIN"]
         h.close()
