@@ -1937,7 +1937,7 @@ void ts_choose_geometry(aps_handle *h) {
     // the others (config 2: 512 tiles of 391 sites, 12.8 us per step against 13.3 with 633 tiles of 316; one launch per
     // step is indifferent: 14.65 against 14.55)
     int own_even = 0;
-    if (h->world == 1 && h->model.field_mode && !(h->model.immobilize && h->model.k_exit > 0.0) && 3 * h->p.K <= 32) {
+    if (h->world == 1 && h->model.field_mode && 3 * h->p.K <= 32) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->p.device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
         const int64_t target = 2LL * cus / std::max(h->E, 1);
@@ -1949,6 +1949,8 @@ void ts_choose_geometry(aps_handle *h) {
     if (const char *env = std::getenv("APS_TS_R")) { const int r = std::atoi(env); if (ts_kernel(false, true, r, true)) { h->ts_RS = r; own_even = 0; } }
     h->ts_own = own_even ? own_even : 64 * h->ts_RS - 4;
     if (const char *env = std::getenv("APS_TS_OWN")) { const int o = std::atoi(env); if (o >= 32 * h->ts_RS && o <= 64 * h->ts_RS - 4) h->ts_own = o; }
+    // a last tile of one or two sites (the resident loop wants three: its neighbour's halo must lie inside it): slightly smaller tiles
+    while (h->ts_own > 32 * h->ts_RS && L > h->ts_own && (L % h->ts_own == 1 || L % h->ts_own == 2)) h->ts_own -= 1;
     h->ts_ntile = (L + h->ts_own - 1) / h->ts_own;
     h->ts_dcap = (int)std::max<int64_t>(2, std::min<int64_t>(2LL * h->p.K * h->ts_own, 2 * h->p.n_particles));
     h->ts_table_in_lds = ts_lds_layout(h->tlen, true, h->ts_RS, h->ts_own, h->p.K, ts_wbytes(h)).total <= 160 * 1024;

@@ -48,6 +48,7 @@ LOOP_CASES = [
          k_on=4.0, k_off=0.5, k_exit=2.0),
     dict(tag="dense_diffusive", L=1280, K=1, sigma=0.05, frac=0.9, rate_diffusion=6.0),
     dict(tag="ragged_last_tile", L=60 * 7 + 5, K=1, sigma=0.03, frac=0.5),
+    dict(tag="last_tile_of_two_sites_avoided", L=60 * 6 + 2, K=1, sigma=0.03, frac=0.5),   # (the geometry shrinks the tiles by a site)
     dict(tag="single_tile_torus", L=50, K=2, sigma=0.1, periodic=True, frac=0.5),
     # more deposits of one class in reach than a pooled list holds (1040): the entries that find it full are swept one by one
     dict(tag="overflowing_lists_torus", L=1200, K=3, sigma=0.4, periodic=True, frac=0.95, rate_diffusion=6.0),
@@ -166,8 +167,8 @@ def test_resident_loop_ensembles(capi):
 
 
 def test_not_eligible_falls_back_silently(capi):
-    """A global mean field, or a last tile shorter than three sites: one launch per step, same results."""
-    for case, reason in [(dict(L=600, K=1, sigma=0.0), "global"), (dict(L=60 * 6 + 2, K=1, sigma=0.03), "three")]:
+    """A global mean field: one launch per step, same results."""
+    for case, reason in [(dict(L=600, K=1, sigma=0.0), "global")]:
         par = params(**case)
         rng = np.random.default_rng(2)
         N = par.L * par.K // 2
