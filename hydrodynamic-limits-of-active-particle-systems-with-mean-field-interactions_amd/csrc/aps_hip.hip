@@ -2006,7 +2006,8 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
         if (field_only) return fail(h, APS_ERR_STATE, "tiles, convolution: no deposits are ever pending");
         a.tile_lo = 0;
         const dim3 grid((unsigned)td_tiles(h->p.L), (unsigned)h->E), block(FU_THREADS);
-        const void *fn = h->p.K == 1 ? reinterpret_cast<const void *>(&tile_dense<true>) : reinterpret_cast<const void *>(&tile_dense<false>);
+        const void *fn = h->f32 ? (h->p.K == 1 ? reinterpret_cast<const void *>(&tile_dense<true, true>) : reinterpret_cast<const void *>(&tile_dense<false, true>))
+                                : (h->p.K == 1 ? reinterpret_cast<const void *>(&tile_dense<true, false>) : reinterpret_cast<const void *>(&tile_dense<false, false>));
         void *args[] = {(void *)&a};
         if (h->profiling && h->prof_dispatch) HIP_TRY(h, hipExtLaunchKernel(fn, grid, block, args, td_lds_bytes(h->p.K), h->stream, h->k_start, h->k_stop, 0));
         else HIP_TRY(h, hipLaunchKernel(fn, grid, block, args, td_lds_bytes(h->p.K), h->stream));
@@ -2050,111 +2051,132 @@ int launch_tile_step(aps_handle *h, bool field_only = false) {
 int launch_ntt_conv(aps_handle *h) {
     const int out = (int)((h->step & 1) ^ 1);                   // the buffer the tile kernel of this step wrote
     const NttPlan &pl = h->ntt;
-    const dim3 grid((unsigned)(((size_t)1 << pl.m) / NTT_TILE), 2u, (unsigned)h->E), block(NTT_THREADS);   // y: the two signals
+    const unsigned tiles = (unsigned)(((size_t)1 << pl.m) / NTT_TILE);
+    const dim3 grid_e(tiles, 2u, (unsigned)h->E), grid_p(tiles, 2u, (unsigned)(h->E * pl.np)), block(NTT_THREADS);   // y: the two signals; z: ensembles (x primes)
+    void *ws = h->f32 ? (void *)h->d_wsi[out] : (void *)h->d_wsb[out];
     int rc;
     const bool timed = h->profiling && h->prof_dispatch;
-#define NTT_STRIDED(AXIS, INV, A_, CSIG, WS, FLAG) do { if ((rc = prof_mark(h, KIND_NTT))) return rc; \
-        ntt_launch_strided<AXIS, INV>(A_, grid, block, h->stream, h->k_start, h->k_stop, timed, pl, h->d_ntt_sig, CSIG, WS, FLAG); } while (0)
+    // the first and the last sweep take every prime inside the workgroup (grid over the ensembles), the launches in between one prime per workgroup
+#define NTT_STRIDED(AXIS, INV, NP_, GRID, A_, CSIG, WS, FLAG) do { if ((rc = prof_mark(h, KIND_NTT))) return rc; \
+        ntt_launch_strided<AXIS, INV, NP_>(A_, GRID, block, h->stream, h->k_start, h->k_stop, timed, pl, h->d_ntt_sig, CSIG, WS, FLAG); } while (0)
+#define NTT_ENDS(AXIS, INV, A_, CSIG, WS) do { if (pl.np == 2) NTT_STRIDED(2, INV, 2, grid_e, A_, CSIG, WS, 1); else NTT_STRIDED(AXIS, INV, 1, grid_e, A_, CSIG, WS, 1); } while (0)
     if (h->ntt_fused) {                                         // i2 sweep, the whole middle in one launch, i2 sweep back
-        NTT_STRIDED(2, false, pl.a2, h->d_ntt_csig, (int2 *)nullptr, 1);
+        NTT_ENDS(2, false, pl.a2, h->d_ntt_csig, nullptr);
         if ((rc = prof_mark(h, KIND_NTT))) return rc;
-        APS_K(h, ntt_mid, dim3(1u << pl.a2, 2u, (unsigned)h->E), dim3(NTT_MID_THREADS), NTT_MID_LDS, pl, h->d_ntt_sig, pl.whatp);
-        NTT_STRIDED(2, true, pl.a2, (int *)nullptr, h->d_wsi[out], 1);
+        APS_K(h, ntt_mid, dim3(1u << pl.a2, 2u, (unsigned)(h->E * pl.np)), dim3(NTT_MID_THREADS), NTT_MID_LDS, pl, h->d_ntt_sig);
+        NTT_ENDS(2, true, pl.a2, (int *)nullptr, ws);
         HIP_TRY(h, hipGetLastError());
         h->field_pending = false;
         return APS_OK;
     }
     if (pl.a2 > 0) {
-        NTT_STRIDED(2, false, pl.a2, h->d_ntt_csig, (int2 *)nullptr, 1);
-        NTT_STRIDED(1, false, pl.a1, (int *)nullptr, (int2 *)nullptr, 0);
-    } else NTT_STRIDED(1, false, pl.a1, h->d_ntt_csig, (int2 *)nullptr, 1);
+        NTT_ENDS(2, false, pl.a2, h->d_ntt_csig, nullptr);
+        NTT_STRIDED(1, false, 1, grid_p, pl.a1, (int *)nullptr, nullptr, 0);
+    } else NTT_ENDS(1, false, pl.a1, h->d_ntt_csig, nullptr);
     if ((rc = prof_mark(h, KIND_NTT))) return rc;
-    APS_K(h, (ntt_contig<false>), grid, block, 0, pl, h->d_ntt_sig);
+    APS_K(h, (ntt_contig<false>), grid_p, block, 0, pl, h->d_ntt_sig);
     if (pl.a2 > 0) {
-        NTT_STRIDED(1, true, pl.a1, (int *)nullptr, (int2 *)nullptr, 0);
-        NTT_STRIDED(2, true, pl.a2, (int *)nullptr, h->d_wsi[out], 1);
-    } else NTT_STRIDED(1, true, pl.a1, (int *)nullptr, h->d_wsi[out], 1);
+        NTT_STRIDED(1, true, 1, grid_p, pl.a1, (int *)nullptr, nullptr, 0);
+        NTT_ENDS(2, true, pl.a2, (int *)nullptr, ws);
+    } else NTT_ENDS(1, true, pl.a1, (int *)nullptr, ws);
+#undef NTT_ENDS
 #undef NTT_STRIDED
     HIP_TRY(h, hipGetLastError());
     h->field_pending = false;                                   // nothing is left in deposit lists: ws[out] is the field of the new cells
     return APS_OK;
 }
 
-// eligibility and tables of the convolution; called from aps_create once the geometry and the integer table exist
+// eligibility and tables of the convolution; called from aps_create once the geometry and the (integer) table exist
 int ntt_setup(aps_handle *h) {
     h->ntt_on = false;
     const char *env = std::getenv("APS_NTT");
     if (env && env[0] == '0') return APS_OK;
     const bool forced = env && env[0] == '1';
-    if (!is_tiles(h) || !h->f32 || !h->model.field_mode || h->p.periodic || h->world != 1) return APS_OK;
+    if (!is_tiles(h) || !h->model.field_mode || h->p.periodic || h->world != 1) return APS_OK;
     if (h->ts_table_in_lds && !forced) return APS_OK;           // the in-LDS sweep (and the resident loop) is faster for short tables
     const int Rt = h->tlen - 1, L = h->p.L;
-    if (!(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;   // one wall image per deposit at most (tile_step's mirror_ok)
+    if (!(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;   // one wall image per deposit at most
     int m = 14;
     while (((int64_t)1 << m) < (int64_t)L + 2 * Rt) ++m;
-    if (m > 21 || td_lds_bytes(h->p.K) > 160 * 1024) return APS_OK;
-    if (td_lds_bytes(h->p.K) > 48 * 1024 &&                     // frames of tile_dense with many cells per site
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_lds_bytes(h->p.K)) != hipSuccess) {
-        (void)hipGetLastError();
-        return APS_OK;
+    const int np = h->f32 ? 1 : 2;                              // the binary64 field: two primes, put together by the last sweep
+    if (m > 21 || (np == 2 && m < 15) || td_lds_bytes(h->p.K) > 160 * 1024) return APS_OK;
+    if (td_lds_bytes(h->p.K) > 48 * 1024) {                     // frames of tile_dense with many cells per site
+        const void *fn = h->f32 ? reinterpret_cast<const void *>(&tile_dense<false, true>) : reinterpret_cast<const void *>(&tile_dense<false, false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_lds_bytes(h->p.K)) != hipSuccess) { (void)hipGetLastError(); return APS_OK; }
     }
-    // exactness: |dW|, |dS| <= 2 K sum_d w(d) must stay below P / 2
+    // exactness: |dW|, |dS| <= 2 K sum_d w(d) in grid units must stay below half the modulus (32-bit field: P0; binary64: P0 P1 = 2^61.7)
     double wsum = 0.0;
     for (int t = 0; t < h->tlen; ++t) wsum += std::ldexp(h->table[(size_t)t], h->q) * (t ? 2.0 : 1.0);
-    if (2.0 * h->p.K * wsum >= 0.5 * (double)NTT_P) return APS_OK;
+    if (2.0 * h->p.K * wsum >= 0.5 * (np == 1 ? (double)NTT_PRIMES[0] : (double)NTT_PRIMES[0] * (double)NTT_PRIMES[1])) return APS_OK;
     NttPlan &pl = h->ntt;
-    pl.m = m; ntt_split(m, pl.a0, pl.a1, pl.a2); pl.L = L; pl.Rt = Rt;
-    NttTables T;
-    ntt_build_tables(m, T);
+    pl.m = m; ntt_split(m, pl.a0, pl.a1, pl.a2); pl.L = L; pl.Rt = Rt; pl.E = h->E; pl.np = np;
+    pl.crt_inv = ntt_powmod(NTT_PRIMES[0] % NTT_PRIMES[1], NTT_PRIMES[1] - 2ull, NTT_PRIMES[1]);
+    pl.unit = std::ldexp(1.0, -h->q);
     const size_t M = (size_t)1 << m;
-    const size_t o_wr = 0, o_t1 = o_wr + T.wr.size(), o_hi = o_t1 + T.t1.size(), o_lo = o_hi + T.t2hi.size(), o_what = o_lo + T.t2lo.size(), o_whatp = o_what + M, total = o_whatp + M;
+    NttTables T[2];
+    for (int k = 0; k < np; ++k) ntt_build_tables(m, NTT_PRIMES[k], NTT_ROOTS[k], T[k]);
+    const size_t o_wr = 0, o_t1 = o_wr + T[0].wr.size(), o_hi = o_t1 + T[0].t1.size(), o_lo = o_hi + T[0].t2hi.size(), o_what = o_lo + T[0].t2lo.size(),
+                 o_whatp = o_what + M, per_prime = o_whatp + M;
     int rc;
-    if ((rc = dev_alloc(h, &h->d_ntt_tab, total)) || (rc = dev_alloc(h, &h->d_ntt_sig, (size_t)h->E * 2 * M)) || (rc = dev_alloc(h, &h->d_ntt_csig, (size_t)h->E * 2 * M))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_wr, T.wr.data(), T.wr.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_t1, T.t1.data(), T.t1.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_hi, T.t2hi.data(), T.t2hi.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_lo, T.t2lo.data(), T.t2lo.size() * 4, hipMemcpyHostToDevice, h->stream));
-    pl.wr = h->d_ntt_tab + o_wr; pl.t1 = h->d_ntt_tab + o_t1; pl.t2hi = h->d_ntt_tab + o_hi; pl.t2lo = h->d_ntt_tab + o_lo; pl.what = h->d_ntt_tab + o_what; pl.whatp = h->d_ntt_tab + o_whatp;
-    // spectrum of the table: w(|d|) at index d mod M, forward sweeps only, times 1 / M
-    std::vector<uint32_t> wext(2 * M, 0u);
-    for (int t = 0; t < h->tlen; ++t) {
-        const uint32_t v = (uint32_t)(int)std::ldexp(h->table[(size_t)t], h->q);
-        wext[(size_t)t] = v;
-        if (t) wext[M - (size_t)t] = v;
+    if ((rc = dev_alloc(h, &h->d_ntt_tab, per_prime * np)) || (rc = dev_alloc(h, &h->d_ntt_sig, (size_t)np * h->E * 2 * M)) ||
+        (rc = dev_alloc(h, &h->d_ntt_csig, (size_t)h->E * 2 * M))) return rc;
+    for (int k = 0; k < np; ++k) {
+        uint32_t *tb = h->d_ntt_tab + (size_t)k * per_prime;
+        HIP_TRY(h, hipMemcpyAsync(tb + o_wr, T[k].wr.data(), T[k].wr.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(tb + o_t1, T[k].t1.data(), T[k].t1.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(tb + o_hi, T[k].t2hi.data(), T[k].t2hi.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(tb + o_lo, T[k].t2lo.data(), T[k].t2lo.size() * 4, hipMemcpyHostToDevice, h->stream));
+        NttPrime &pp = pl.pr[k];
+        pp.P = NTT_PRIMES[k]; pp.md.P = (double)NTT_PRIMES[k]; pp.md.Pinv = 1.0 / (double)NTT_PRIMES[k];
+        pp.wr = tb + o_wr; pp.t1 = tb + o_t1; pp.t2hi = tb + o_hi; pp.t2lo = tb + o_lo; pp.what = tb + o_what; pp.whatp = tb + o_whatp;
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_sig, wext.data(), wext.size() * 4, hipMemcpyHostToDevice, h->stream));
-    const dim3 grid((unsigned)(M / NTT_TILE), 1u, 1u), block(NTT_THREADS);
-    if (pl.a2 > 0) ntt_launch_strided<2, false>(pl.a2, grid, block, h->stream, nullptr, nullptr, false, pl, h->d_ntt_sig, nullptr, nullptr, 0);
-    ntt_launch_strided<1, false>(pl.a1, grid, block, h->stream, nullptr, nullptr, false, pl, h->d_ntt_sig, nullptr, nullptr, 0);
-    hipLaunchKernelGGL((ntt_contig<true>), grid, block, 0, h->stream, pl, h->d_ntt_sig);
-    HIP_TRY(h, hipGetLastError());
-    std::vector<uint32_t> spec(M);
-    HIP_TRY(h, hipMemcpyAsync(spec.data(), h->d_ntt_sig, M * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const uint32_t minv = ntt_powmod((uint32_t)(M % NTT_P), NTT_P - 2ull);
-    for (size_t i = 0; i < M; ++i) spec[i] = ntt_mulmod_u64(spec[i], minv);
-    HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_what, spec.data(), M * 4, hipMemcpyHostToDevice, h->stream));
+    if (np == 1) pl.pr[1] = pl.pr[0];
     // the three middle launches as one (ntt_mid): 128 x 128 slabs, at least two of them; APS_NTT_FUSED=0 keeps the five launches
     const char *fenv = std::getenv("APS_NTT_FUSED");
     h->ntt_fused = pl.a0 == 7 && pl.a1 == 7 && pl.a2 >= 1 && !(fenv && fenv[0] == '0');
-    std::vector<uint32_t> specp;
-    if (h->ntt_fused) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_MID_LDS) != hipSuccess) {
-            (void)hipGetLastError(); h->ntt_fused = false;
+    if (h->ntt_fused && hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_MID_LDS) != hipSuccess) {
+        (void)hipGetLastError(); h->ntt_fused = false;
+    }
+    // spectrum of the table mod every prime: w(|d|) (an integer in grid units) at index d mod M, forward sweeps only, times 1 / M.
+    // One signal per prime in the layout of a plan with one ensemble ([prime][1][W | S][M]: the S halves stay unused).
+    {
+        NttPlan ps = pl;
+        ps.E = 1;
+        std::vector<uint32_t> wext((size_t)np * 2 * M, 0u);
+        for (int k = 0; k < np; ++k)
+            for (int t = 0; t < h->tlen; ++t) {
+                const uint32_t v = (uint32_t)((unsigned long long)std::ldexp(h->table[(size_t)t], h->q) % NTT_PRIMES[k]);
+                wext[(size_t)k * 2 * M + (size_t)t] = v;
+                if (t) wext[(size_t)k * 2 * M + M - (size_t)t] = v;
+            }
+        HIP_TRY(h, hipMemcpyAsync(h->d_ntt_sig, wext.data(), wext.size() * 4, hipMemcpyHostToDevice, h->stream));
+        const dim3 grid((unsigned)(M / NTT_TILE), 1u, (unsigned)np), block(NTT_THREADS);
+        if (pl.a2 > 0) ntt_launch_strided<2, false, 1>(pl.a2, grid, block, h->stream, nullptr, nullptr, false, ps, h->d_ntt_sig, nullptr, nullptr, 0);
+        ntt_launch_strided<1, false, 1>(pl.a1, grid, block, h->stream, nullptr, nullptr, false, ps, h->d_ntt_sig, nullptr, nullptr, 0);
+        hipLaunchKernelGGL((ntt_contig<true>), grid, block, 0, h->stream, ps, h->d_ntt_sig);
+        HIP_TRY(h, hipGetLastError());
+        std::vector<uint32_t> spec(M), specp;
+        for (int k = 0; k < np; ++k) {
+            HIP_TRY(h, hipMemcpyAsync(spec.data(), h->d_ntt_sig + (size_t)k * 2 * M, M * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            const uint32_t P = NTT_PRIMES[k], minv = ntt_powmod((uint32_t)(M % P), P - 2ull, P);
+            for (size_t i = 0; i < M; ++i) spec[i] = ntt_mulmod_u64(spec[i], minv, P);
+            HIP_TRY(h, hipMemcpy(h->d_ntt_tab + (size_t)k * per_prime + o_what, spec.data(), M * 4, hipMemcpyHostToDevice));
+            if (h->ntt_fused) {                                 // the spectrum in the slots' order: slot s holds frequency brev(s)
+                specp.resize(M);
+                auto brev7 = [](size_t v) { size_t r = 0; for (int b = 0; b < 7; ++b) r |= ((v >> b) & 1) << (6 - b); return r; };
+                for (size_t k2 = 0; k2 < (M >> 14); ++k2)
+                    for (size_t s0 = 0; s0 < 128; ++s0)
+                        for (size_t s1 = 0; s1 < 128; ++s1) specp[(k2 << 14) + s0 * 128 + s1] = spec[(k2 << 14) + brev7(s1) * 128 + brev7(s0)];
+                HIP_TRY(h, hipMemcpy(h->d_ntt_tab + (size_t)k * per_prime + o_whatp, specp.data(), M * 4, hipMemcpyHostToDevice));
+            }
         }
     }
-    if (h->ntt_fused) {                                         // the spectrum in the slots' order: slot s holds frequency brev(s)
-        specp.resize(M);
-        auto brev7 = [](size_t v) { size_t r = 0; for (int b = 0; b < 7; ++b) r |= ((v >> b) & 1) << (6 - b); return r; };
-        for (size_t k2 = 0; k2 < (M >> 14); ++k2)
-            for (size_t s0 = 0; s0 < 128; ++s0)
-                for (size_t s1 = 0; s1 < 128; ++s1) specp[(k2 << 14) + s0 * 128 + s1] = spec[(k2 << 14) + brev7(s1) * 128 + brev7(s0)];
-        HIP_TRY(h, hipMemcpyAsync(h->d_ntt_tab + o_whatp, specp.data(), M * 4, hipMemcpyHostToDevice, h->stream));
-    }
-    HIP_TRY(h, hipMemsetAsync(h->d_ntt_sig, 0, (size_t)h->E * 2 * M * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_ntt_sig, 0, (size_t)np * h->E * 2 * M * 4, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // {W, S} need no second buffer: the tile kernel only reads them and the last sweep of the convolution updates them in place
     if (h->d_wsi[1] && h->d_wsi[1] != h->d_wsi[0]) { (void)hipFree(h->d_wsi[1]); h->d_wsi[1] = h->d_wsi[0]; }
+    if (!h->f32 && h->d_wsb[1] && h->d_wsb[1] != h->d_wsb[0]) { (void)hipFree(h->d_wsb[1]); h->d_wsb[1] = h->d_wsb[0]; }
     h->ntt_on = true;
     return APS_OK;
 }
@@ -2761,8 +2783,8 @@ int aps_create(const aps_params *p, aps_handle **out) {
                 (rc = dev_alloc(h, &h->d_wsi[0], EL)) || (rc = dev_alloc(h, &h->d_wsi[1], EL))) return die(rc);
             if (hipMemcpyAsync(h->d_table_i, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "integer table upload failed"; return die(APS_ERR_HIP); }
-            if ((rc = ntt_setup(h))) return die(rc);
         }
+        if ((rc = ntt_setup(h))) return die(rc);
         if (h->world > 1 && (rc = halo_setup(h))) return die(rc);
         const size_t need = ts_lds_layout(h->tlen, h->ts_table_in_lds, h->ts_RS, h->ts_own, p->K, ts_wbytes(h)).total;
         if (need > 160 * 1024) { h->err = "tiles: site capacity too large for the tile kernel's LDS staging"; return die(APS_ERR_ARG); }
@@ -2792,7 +2814,7 @@ void aps_destroy(aps_handle *h) {
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->method == APS_METHOD_TILES) h->d_ws = nullptr;   // an alias of d_wsb[cur] there
     for (int b = 0; b < 2; ++b)
-        for (void *q : {(void *)h->d_wsb[b], (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
+        for (void *q : {(void *)(b == 1 && h->d_wsb[1] == h->d_wsb[0] ? nullptr : h->d_wsb[b]), (void *)h->d_cell[b], (void *)h->d_tdcnt[b], (void *)h->d_tdep[b], (void *)h->d_gpart[b]}) if (q) (void)hipFree(q);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
     if (h->d_flip_tab) (void)hipFree(h->d_flip_tab);
     for (void *q : {(void *)h->d_ntt_sig, (void *)h->d_ntt_tab, (void *)h->d_ntt_csig}) if (q) (void)hipFree(q);

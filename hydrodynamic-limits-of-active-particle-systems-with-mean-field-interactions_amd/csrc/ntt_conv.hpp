@@ -1,4 +1,4 @@
-// ntt_conv.hpp -- the field update of the 32-bit field as ONE exact convolution per step (included by aps_hip.hip inside its
+// ntt_conv.hpp -- the field update as ONE exact convolution per step (included by aps_hip.hip inside its
 // anonymous namespace).
 //
 // Hot path replaced: compute_local_m_field (PARTICLE_solver_CLASS.py:216-246), whose smoothing the reference itself evaluates by
@@ -7,8 +7,11 @@
 // signals on the lattice (a hop: -1 at the old site, +1 at the new one; a flip: -+2 in cS) and w the weight table.  For a table
 // far beyond LDS (BASELINE config 5: 80 001 taps) tile_step's sweep costs deposits x taps = 1.7e9 LDS gathers per step; the
 // convolution theorem costs O(M log M) with M = 2^21 -- and a number-theoretic transform keeps it EXACT: every W, S, dW, dS is
-// an integer (units of 2^-q) of magnitude below 2^29, the prime P = 15 * 2^27 + 1 = 2 013 265 921 exceeds twice that, so the
-// residues mod P determine the integers.  Same bits as the sweep, the oracle and every other formulation.
+// an integer (units of 2^-q) of magnitude below 2^29 (32-bit field), the prime P = 15 * 2^27 + 1 = 2 013 265 921 exceeds twice
+// that, so the residues mod P determine the integers.  Same bits as the sweep, the oracle and every other formulation.
+// The binary64 field (integers below 2^51 in units of its own 2^-q) takes the same transform modulo TWO primes -- the second
+// one 27 * 2^26 + 1 = 1 811 939 329, product 2^61.7 -- and the last sweep puts the two residues together (Chinese remainder:
+// x = r0 + P0 ((r1 - r0) P0^-1 mod P1), centred), exactly.
 //
 // Reflecting walls: the deposits within the table's reach of a wall are entered a second time at their mirror site
 // (-1 - p, 2L - 1 - p), i.e. the signals live on [-Rt, L + Rt) and a plain linear convolution gives the reference's
@@ -24,15 +27,16 @@
 // run at a quarter).
 #pragma once
 
-constexpr uint32_t NTT_P = 2013265921u;          // 15 * 2^27 + 1
-constexpr uint32_t NTT_G = 31u;                  // a primitive root of P
+constexpr uint32_t NTT_PRIMES[2] = {2013265921u, 1811939329u};   // 15 * 2^27 + 1, 27 * 2^26 + 1
+constexpr uint32_t NTT_ROOTS[2] = {31u, 13u};                    // a primitive root of each
+constexpr uint32_t NTT_P = NTT_PRIMES[0];
 constexpr int NTT_TILE = 4096;                   // words of one signal a workgroup holds in LDS
 constexpr int NTT_THREADS = 256;
 
-__host__ __device__ inline uint32_t ntt_mulmod_u64(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) % NTT_P); }
-inline uint32_t ntt_powmod(uint32_t b, unsigned long long e) {
+inline uint32_t ntt_mulmod_u64(uint32_t a, uint32_t b, uint32_t P) { return (uint32_t)(((unsigned long long)a * b) % P); }
+inline uint32_t ntt_powmod(uint32_t b, unsigned long long e, uint32_t P) {
     uint32_t r = 1u;
-    while (e) { if (e & 1ull) r = ntt_mulmod_u64(r, b); b = ntt_mulmod_u64(b, b); e >>= 1; }
+    while (e) { if (e & 1ull) r = ntt_mulmod_u64(r, b, P); b = ntt_mulmod_u64(b, b, P); e >>= 1; }
     return r;
 }
 
@@ -40,30 +44,38 @@ inline uint32_t ntt_powmod(uint32_t b, unsigned long long e) {
 // LDS doubles of EITHER sign whose magnitude the butterflies let grow (a level doubles it at most: below 2^8 * 2 P < 2^39 after
 // the seven levels of a 128-point transform) until the next product brings them back to [0, 2 P).  Quotients are estimated by
 // floor(x / P - 2^-10): never above the true quotient (floor: also for negative x), at most one below it for every product that
-// occurs here (|a| < 2^39, b < 2^32: quotient below 2^40.1, three roundings of 2^-53 relative + the dropped low part l / P <
-// 2^-14 -> error below 2^-11 < 2^-10), so a remainder lies in [0, 2 P) without any correction step.
+// occurs here (|a| < 2^39, b < 2^32, P > 2^30.7: quotient below 2^40.3, three roundings of 2^-53 relative + the dropped low part
+// l / P < 2^-13 -> error below 2^-11 < 2^-10), so a remainder lies in [0, 2 P) without any correction step.
 constexpr double NTT_BIAS = 0.0009765625;                        // 2^-10
+struct NttMod { double P, Pinv; };                               // the prime as a double and its reciprocal (rounded)
 // a * b mod P, lazy: |a| < 2^39, 0 <= b < 2^32 -> [0, 2 P).  Exact: a b = h + l with l from fma; h - q P is a small integer (fma again).
-__device__ __forceinline__ double ntt_mul(double a, double b) {
-    const double Pd = (double)NTT_P, Pinv = 1.0 / (double)NTT_P;
+__device__ __forceinline__ double ntt_mul(const double a, const double b, const NttMod md) {
     const double h = a * b, l = fma(a, b, -h);
-    const double q = floor(fma(h, Pinv, -NTT_BIAS));
-    return fma(-q, Pd, h) + l;
+    const double q = floor(fma(h, md.Pinv, -NTT_BIAS));
+    return fma(-q, md.P, h) + l;
 }
-__device__ __forceinline__ double ntt_red(double v) {             // v an integer, |v| < 2^40 -> [0, 2 P), congruent
-    const double q = floor(fma(v, 1.0 / (double)NTT_P, -NTT_BIAS));
-    return fma(-q, (double)NTT_P, v);
+__device__ __forceinline__ double ntt_red(const double v, const NttMod md) {   // v an integer, |v| < 2^40 -> [0, 2 P), congruent
+    const double q = floor(fma(v, md.Pinv, -NTT_BIAS));
+    return fma(-q, md.P, v);
 }
-__device__ __forceinline__ uint32_t ntt_canon(uint32_t v) { return v >= NTT_P ? v - NTT_P : v; }     // [0, 2 P) -> [0, P)
+__device__ __forceinline__ uint32_t ntt_canon(const uint32_t v, const uint32_t P) { return v >= P ? v - P : v; }     // [0, 2 P) -> [0, P)
 
-struct NttPlan {
-    int m, a0, a1, a2;                     // M = 2^m = R2 R1 R0, R_x = 2^a_x (a0 = 7; a2 = 0: two sweeps only)
-    int L, Rt;                             // lattice sites, table reach; signal index = site + Rt
+struct NttPrime {                          // the tables of one prime (device pointers)
+    uint32_t P;
+    NttMod md;
     const uint32_t *wr;                    // [2][3][64]  w_R^j for the three axes (R0, R1, R2), forward / inverse
     const uint32_t *t1;                    // [2][R1 R2]  w^(+-R0 e)            (twiddle between the i2 and the i1 sweep, e = i1 k2)
     const uint32_t *t2hi, *t2lo;           // [2][M / 1024], [2][1024]: w^(+-e) = hi[e >> 10] lo[e & 1023]   (e = i0 (k2 + R2 k1))
     const uint32_t *what;                  // [M] spectrum of the table in the transform's own output order, times 1 / M
     const uint32_t *whatp;                 // [M] the same in ntt_mid's slot order: [k2][i0-slot][i1-slot], slot s holds frequency brev(s)
+};
+struct NttPlan {
+    int m, a0, a1, a2;                     // M = 2^m = R2 R1 R0, R_x = 2^a_x (a0 = 7; a2 = 0: two sweeps only)
+    int L, Rt;                             // lattice sites, table reach; signal index = site + Rt
+    int E, np;                             // ensembles; primes: 1 (32-bit field: int32 {W, S}) or 2 (binary64 field: double {W, S} = integers * unit)
+    uint32_t crt_inv;                      // P0^-1 mod P1
+    double unit;                           // 2^-q of the binary64 field
+    NttPrime pr[2];                        // signals: [prime][ensemble][W | S][M] words
 };
 
 // B butterfly levels on the 2^B values of one thread.  The values are rows  n + (t << lo_shift), t = 0 .. 2^B - 1, of a transform
@@ -72,7 +84,7 @@ struct NttPlan {
 // N0: n is known to be zero (the second pass): the pairs with j = 0 need no product; otherwise every pair multiplies (w_R^0 = 1
 // for the rare n = j = 0: a branch per butterfly would cost more than the product)
 template <int B, bool N0>
-__device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double *__restrict__ wtab, const int n, const int lo_shift, const int s0) {
+__device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double *__restrict__ wtab, const int n, const int lo_shift, const int s0, const NttMod md) {
     // a level at most doubles the magnitude of its values (sums and differences; a product is back in [0, 2 P))
 #pragma unroll
     for (int s = 0; s < B; ++s) {
@@ -85,7 +97,7 @@ __device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double
             x[u] = xa + xb;
             const double d = xa - xb;                                      // either sign: the quotient estimate of ntt_mul floors
             const int e = (n + (j << lo_shift)) << (s0 + s);               // < 64
-            if (N0 && j == 0) x[v] = d; else x[v] = ntt_mul(d, wtab[e]);
+            if (N0 && j == 0) x[v] = d; else x[v] = ntt_mul(d, wtab[e], md);
         }
     }
 }
@@ -93,7 +105,7 @@ __device__ __forceinline__ void ntt_reg_levels(double (&x)[1 << B], const double
 // Transform of size 2^A (natural order in, bit-reversed order out) of the NC = 2^lg_nc columns of one signal held in LDS, element
 // (row r, column c) at buf[r * ld + c] (doubles, lazy residues): two register passes (2^AH = 16 rows a thread, then 2^AL = 8).
 template <int A>
-__device__ __forceinline__ void ntt_lds_transform(double *buf, const int lg_nc, const int ld, const double *__restrict__ wtab, const int t) {
+__device__ __forceinline__ void ntt_lds_transform(double *buf, const int lg_nc, const int ld, const double *__restrict__ wtab, const int t, const NttMod md) {
     constexpr int AH = A < 4 ? A : 4, AL = A - AH;
     const int NC = 1 << lg_nc;
     for (int w = t; w < (NC << AL); w += NTT_THREADS) {                    // pass 1: rows n + (tt << AL)
@@ -101,9 +113,9 @@ __device__ __forceinline__ void ntt_lds_transform(double *buf, const int lg_nc, 
         double x[1 << AH];
 #pragma unroll
         for (int tt = 0; tt < (1 << AH); ++tt) x[tt] = buf[(n + (tt << AL)) * ld + c];
-        ntt_reg_levels<AH, false>(x, wtab, n, AL, 0);
+        ntt_reg_levels<AH, false>(x, wtab, n, AL, 0, md);
 #pragma unroll
-        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = AL > 0 ? x[tt] : ntt_red(x[tt]);   // (reduced by the last pass)
+        for (int tt = 0; tt < (1 << AH); ++tt) buf[(n + (tt << AL)) * ld + c] = AL > 0 ? x[tt] : ntt_red(x[tt], md);   // (reduced by the last pass)
     }
     __syncthreads();
     if constexpr (AL > 0) {
@@ -112,9 +124,9 @@ __device__ __forceinline__ void ntt_lds_transform(double *buf, const int lg_nc, 
             double x[1 << AL];
 #pragma unroll
             for (int v = 0; v < (1 << AL); ++v) x[v] = buf[((u << AL) + v) * ld + c];
-            ntt_reg_levels<AL, true>(x, wtab, 0, 0, AH);
+            ntt_reg_levels<AL, true>(x, wtab, 0, 0, AH, md);
 #pragma unroll
-            for (int v = 0; v < (1 << AL); ++v) buf[((u << AL) + v) * ld + c] = ntt_red(x[v]);
+            for (int v = 0; v < (1 << AL); ++v) buf[((u << AL) + v) * ld + c] = ntt_red(x[v], md);
         }
         __syncthreads();
     }
@@ -124,10 +136,13 @@ __device__ __forceinline__ int ntt_bitrev(int v, int bits) { return (int)(__brev
 // ---- sweep along a strided axis (i2: stride R0 R1, or i1: stride R0): a workgroup takes NC consecutive words (same other digits)
 // for all R = 2^A values of the axis digit, of one signal (blockIdx.y).
 // first forward sweep (INIT): the input are the deposit signals -- int32 coefficients, cleared behind the read -- instead of
-// residues; last inverse sweep (FINAL): the result is added to {W, S} of the sites.
+// residues; last inverse sweep (FINAL): the result is added to {W, S} of the sites.  Both take every prime of the plan in turn
+// (blockIdx.z = ensemble): the coefficients are read once, and the last sweep needs all residues of a word to put the integer
+// together; in between a launch covers the primes by blockIdx.z = prime * E + ensemble.
 // AXIS 1: forward: multiply by w^(R0 i1 k2), transform over i1; inverse: transform, multiply by w^(-R0 i1 k2).
-template <int AXIS, bool INV, int A>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uint32_t *__restrict__ data, int *__restrict__ csig, int2 *__restrict__ ws, const int init_or_final) {
+// NP: primes of the plan (2 is only instantiated for the i2 sweeps: the binary64 field wants m >= 15)
+template <int AXIS, bool INV, int A, int NP>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uint32_t *__restrict__ data, int *__restrict__ csig, void *__restrict__ ws, const int init_or_final) {
     __shared__ double buf[NTT_TILE + 128];
     __shared__ double wtab[64];
     const int t = threadIdx.x, sgl = blockIdx.y;                 // one signal (0: W, 1: S) per workgroup
@@ -139,49 +154,71 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
     const size_t per_outer = stride / NC;                        // tiles per value of the digits above the axis
     const size_t outer = blockIdx.x / per_outer, inner0 = (blockIdx.x % per_outer) * NC;
     const size_t base = outer * stride * R + inner0;             // word index of (axis digit 0, first column)
-    uint32_t *sig0 = data + ((size_t)blockIdx.z * 2 + sgl) * M;
-    int *c0 = csig ? csig + ((size_t)blockIdx.z * 2 + sgl) * M : nullptr;
+    const bool first = !INV && init_or_final, last = INV && init_or_final;
+    const int ens = (first || last) ? (int)blockIdx.z : (int)blockIdx.z % pl.E;
+    const int npr = (first || last) ? NP : 1;
     constexpr int ld = NC + 1;
-    if (t < 64) wtab[t] = (double)pl.wr[(INV ? 192 : 0) + (AXIS == 2 ? 128 : 64) + t];
-    // ---- load (row r = axis digit, column c): + twiddle of the i1 sweep going forward
     const int k2 = (int)outer;                                   // AXIS 1: the digit above (slot i2 holds k2)
     constexpr int NI = NTT_TILE / NTT_THREADS;                   // words per thread: all their loads are issued before the first is used
-    {
-        uint32_t raw[NI], twv[NI];
+    int coef[NI];                                                // INIT: the deposit coefficients, read once for all primes
+    uint32_t res0[NP > 1 ? NI : 1];                              // FINAL with two primes: the residues mod the first one
+    if (first) {
+        int *c0 = csig + ((size_t)ens * 2 + sgl) * M;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
-            const size_t g = base + (size_t)r * stride + c;
-            raw[u] = (!INV && init_or_final) ? (uint32_t)c0[g] : sig0[g];
-            twv[u] = (AXIS == 1 && !INV) ? pl.t1[(size_t)r * k2] : 1u;       // w^(R0 i1 k2), i1 = r
+            coef[u] = c0[base + (size_t)r * stride + c];
         }
 #pragma unroll
-        for (int u = 0; u < NI; ++u) {
+        for (int u = 0; u < NI; ++u) {                           // cleared for the next step
             const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
-            double v0;
-            if (!INV && init_or_final) {                         // deposit coefficients (small signed integers), cleared for the next step
-                const int x0 = (int)raw[u];
-                if (x0) c0[base + (size_t)r * stride + c] = 0;
-                v0 = (double)x0;
-            } else v0 = (double)raw[u];
-            if (AXIS == 1 && !INV) v0 = ntt_mul(v0, (double)twv[u]);
-            buf[r * ld + c] = v0;
+            if (coef[u]) c0[base + (size_t)r * stride + c] = 0;
         }
     }
-    __syncthreads();
-    ntt_lds_transform<A>(buf, lg_nc, ld, wtab, t);
-    // ---- store, un-permuting the bit-reversed output: slot r gets the value of frequency r
-    {
+#pragma unroll 1
+    for (int q = 0; q < npr; ++q) {
+        const int pi = (first || last) ? q : (int)blockIdx.z / pl.E;
+        const NttPrime &pp = pl.pr[pi];
+        const NttMod md = pp.md;
+        uint32_t *sig0 = data + (((size_t)pi * pl.E + ens) * 2 + sgl) * M;
+        if (q) __syncthreads();                                  // everyone has read the previous prime's result out of LDS
+        if (t < 64) wtab[t] = (double)pp.wr[(INV ? 192 : 0) + (AXIS == 2 ? 128 : 64) + t];
+        // ---- load (row r = axis digit, column c): + twiddle of the i1 sweep going forward
+        {
+            uint32_t raw[NI], twv[NI];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+                const size_t g = base + (size_t)r * stride + c;
+                raw[u] = first ? 0u : sig0[g];
+                twv[u] = (AXIS == 1 && !INV) ? pp.t1[(size_t)r * k2] : 1u;       // w^(R0 i1 k2), i1 = r
+            }
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+                double v0 = first ? (double)coef[u] : (double)raw[u];            // (coefficients: small signed integers)
+                if (AXIS == 1 && !INV) v0 = ntt_mul(v0, (double)twv[u], md);
+                buf[r * ld + c] = v0;
+            }
+        }
+        __syncthreads();
+        ntt_lds_transform<A>(buf, lg_nc, ld, wtab, t, md);
+        // ---- store, un-permuting the bit-reversed output: slot r gets the value of frequency r
         uint32_t twv[NI];
-        int old_w[NI];
+        int old_w[NP == 1 ? NI : 1];                             // FINAL: the sites' W (or S) this thread will add to: int32 field
+        double old_d[NP > 1 ? NI : 1];                           // ... binary64 field
+        const bool combine = last && q == npr - 1;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
-            twv[u] = (AXIS == 1 && INV) ? pl.t1[((size_t)1 << (pl.a1 + pl.a2)) + (size_t)r * k2] : 1u;   // w^(-R0 i1 k2): the result index r is i1
-            old_w[u] = 0;
-            if (INV && init_or_final) {                          // the sites' {W, S} this thread will add to
+            twv[u] = (AXIS == 1 && INV) ? pp.t1[((size_t)1 << (pl.a1 + pl.a2)) + (size_t)r * k2] : 1u;   // w^(-R0 i1 k2): the result index r is i1
+            if constexpr (NP == 1) old_w[u] = 0; else old_d[u] = 0.0;
+            if (combine) {
                 const long long site = (long long)(base + (size_t)r * stride + c) - pl.Rt;
-                if (site >= 0 && site < pl.L) old_w[u] = reinterpret_cast<const int *>(ws + (size_t)blockIdx.z * pl.L + site)[sgl];
+                if (site >= 0 && site < pl.L) {
+                    if constexpr (NP == 1) old_w[u] = reinterpret_cast<const int *>(reinterpret_cast<const int2 *>(ws) + (size_t)ens * pl.L + site)[sgl];
+                    else old_d[u] = reinterpret_cast<const double *>(reinterpret_cast<const double2 *>(ws) + (size_t)ens * pl.L + site)[sgl];
+                }
             }
         }
 #pragma unroll
@@ -189,14 +226,26 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
             const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
             double d0 = buf[ntt_bitrev(r, A) * ld + c];
             const size_t g = base + (size_t)r * stride + c;
-            if (AXIS == 1 && INV) d0 = ntt_mul(d0, (double)twv[u]);
+            if (AXIS == 1 && INV) d0 = ntt_mul(d0, (double)twv[u], md);
             const uint32_t v0 = (uint32_t)d0;
-            if (INV && init_or_final) {                          // natural order again: word g is the change of W (or S) at site g - Rt
-                const long long site = (long long)g - pl.Rt;
-                const uint32_t vc = ntt_canon(v0);
-                if (site >= 0 && site < pl.L && vc)
-                    reinterpret_cast<int *>(ws + (size_t)blockIdx.z * pl.L + site)[sgl] = old_w[u] + (vc > NTT_P / 2 ? (int)(vc - NTT_P) : (int)vc);
-            } else sig0[g] = v0;
+            if (!last) { sig0[g] = v0; continue; }
+            // natural order again: word g is the change of W (or S) at site g - Rt
+            const long long site = (long long)g - pl.Rt;
+            const uint32_t vc = ntt_canon(v0, pp.P);
+            if (!combine) { if constexpr (NP > 1) res0[u] = vc; continue; }
+            if (site < 0 || site >= pl.L) continue;
+            if constexpr (NP == 1) {
+                if (vc) reinterpret_cast<int *>(reinterpret_cast<int2 *>(ws) + (size_t)ens * pl.L + site)[sgl] = old_w[u] + (vc > pp.P / 2 ? (int)(vc - pp.P) : (int)vc);
+            } else {
+                // Chinese remainder: x = r0 + P0 t, t = (r1 - r0) P0^-1 mod P1; centred: |x| < P0 P1 / 2 by construction of the weight grid
+                const uint32_t P0 = pl.pr[0].P, P1 = pp.P, r0 = res0[u];
+                const uint32_t r0m = r0 >= P1 ? r0 - P1 : r0;                     // P0 < 2 P1
+                const uint32_t dd = vc >= r0m ? vc - r0m : vc + P1 - r0m;
+                const uint32_t tt = ntt_canon((uint32_t)ntt_mul((double)dd, (double)pl.crt_inv, md), P1);
+                const unsigned long long x = (unsigned long long)r0 + (unsigned long long)P0 * tt, PP = (unsigned long long)P0 * P1;
+                const long long xs = x > PP / 2 ? (long long)(x - PP) : (long long)x;
+                if (xs) reinterpret_cast<double *>(reinterpret_cast<double2 *>(ws) + (size_t)ens * pl.L + site)[sgl] = old_d[u] + (double)xs * pl.unit;
+            }
         }
     }
 }
@@ -212,10 +261,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
     constexpr int A0 = 7, R0 = 1 << A0, lg_nr = 12 - A0, NR = 1 << lg_nr;   // rows per tile
     const size_t M = (size_t)1 << pl.m;
     const size_t row0 = (size_t)blockIdx.x * NR;                 // row = (i1-slot, i2-slot) = k1 + R1 k2
+    const NttPrime &pp = pl.pr[blockIdx.z / pl.E];              // blockIdx.z = prime * E + ensemble: the signals are laid out in that order
+    const NttMod md = pp.md;
     uint32_t *sig0 = data + ((size_t)blockIdx.z * 2 + sgl) * M;
     constexpr int ld = NR + 1;                                   // element (transform row i0, tile row r) at i0 * ld + r
     const int R1m = (1 << pl.a1) - 1;
-    if (t < 128) wtab[t >> 6][t & 63] = (double)pl.wr[(t >> 6) * 192 + (t & 63)];
+    if (t < 128) wtab[t >> 6][t & 63] = (double)pp.wr[(t >> 6) * 192 + (t & 63)];
     constexpr int NI = NTT_TILE / NTT_THREADS;
     auto tw2_index = [&](const size_t row, const int i0, size_t &ihi, size_t &ilo) {
         const int k1 = (int)(row & (size_t)R1m), k2 = (int)(row >> pl.a1);
@@ -231,22 +282,22 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
             const size_t g = (row0 + r) * R0 + i0;
             size_t ihi, ilo;
             tw2_index(row0 + r, i0, ihi, ilo);
-            raw[u] = sig0[g]; hi[u] = pl.t2hi[ihi]; lo[u] = pl.t2lo[ilo];
-            whatv[u] = FWD_ONLY ? 0u : pl.what[g];
+            raw[u] = sig0[g]; hi[u] = pp.t2hi[ihi]; lo[u] = pp.t2lo[ilo];
+            whatv[u] = FWD_ONLY ? 0u : pp.what[g];
         }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
-            buf[i0 * ld + r] = ntt_mul((double)raw[u], ntt_mul((double)hi[u], (double)lo[u]));
+            buf[i0 * ld + r] = ntt_mul((double)raw[u], ntt_mul((double)hi[u], (double)lo[u], md), md);
         }
     }
     __syncthreads();
-    ntt_lds_transform<A0>(buf, lg_nr, ld, wtab[0], t);
+    ntt_lds_transform<A0>(buf, lg_nr, ld, wtab[0], t, md);
     if (FWD_ONLY) {
         for (int w = t; w < NTT_TILE; w += NTT_THREADS) {
             const int i0 = w & (R0 - 1), r = w >> A0;
             const int src = ntt_bitrev(i0, A0);
-            sig0[(row0 + r) * R0 + i0] = ntt_canon((uint32_t)buf[src * ld + r]);      // (the table's spectrum is kept canonical)
+            sig0[(row0 + r) * R0 + i0] = ntt_canon((uint32_t)buf[src * ld + r], pp.P);      // (the table's spectrum is kept canonical)
         }
         return;
     }
@@ -257,7 +308,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
         const int w = t + u * NTT_THREADS;
         const int i0 = w & (R0 - 1), r = w >> A0;
         const int src = ntt_bitrev(i0, A0);
-        keep0[u] = ntt_mul(buf[src * ld + r], (double)whatv[u]);
+        keep0[u] = ntt_mul(buf[src * ld + r], (double)whatv[u], md);
     }
     __syncthreads();
 #pragma unroll
@@ -267,7 +318,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
         buf[i0 * ld + r] = keep0[u];
     }
     __syncthreads();
-    ntt_lds_transform<A0>(buf, lg_nr, ld, wtab[1], t);
+    ntt_lds_transform<A0>(buf, lg_nr, ld, wtab[1], t, md);
     {
         uint32_t hi[NI], lo[NI];
         const size_t nhi = M >> 10;
@@ -276,12 +327,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
             const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
             size_t ihi, ilo;
             tw2_index(row0 + r, i0, ihi, ilo);
-            hi[u] = pl.t2hi[nhi + ihi]; lo[u] = pl.t2lo[1024 + ilo];
+            hi[u] = pp.t2hi[nhi + ihi]; lo[u] = pp.t2lo[1024 + ilo];
         }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int w = t + u * NTT_THREADS, i0 = w & (R0 - 1), r = w >> A0;
-            const double v0 = ntt_mul(buf[ntt_bitrev(i0, A0) * ld + r], ntt_mul((double)hi[u], (double)lo[u]));
+            const double v0 = ntt_mul(buf[ntt_bitrev(i0, A0) * ld + r], ntt_mul((double)hi[u], (double)lo[u], md), md);
             sig0[(row0 + r) * R0 + i0] = (uint32_t)v0;
         }
     }
@@ -303,24 +354,24 @@ constexpr int NTT_MID_LD = 129;
 constexpr size_t NTT_MID_LDS = ((size_t)128 * NTT_MID_LD + 128) * sizeof(double);
 constexpr int NTT_MID_WORDS = 128 * 128;
 
-__device__ __forceinline__ double ntt_tw2(const NttPlan &pl, const bool inv, const unsigned e) {     // w^(+-e), e < M, lazy
-    const size_t nhi = ((size_t)1 << pl.m) >> 10;
-    return ntt_mul((double)pl.t2hi[(inv ? nhi : 0) + (e >> 10)], (double)pl.t2lo[(inv ? 1024u : 0u) + (e & 1023u)]);
+__device__ __forceinline__ double ntt_tw2(const NttPrime &pp, const int m, const bool inv, const unsigned e) {     // w^(+-e), e < M, lazy
+    const size_t nhi = ((size_t)1 << m) >> 10;
+    return ntt_mul((double)pp.t2hi[(inv ? nhi : 0) + (e >> 10)], (double)pp.t2lo[(inv ? 1024u : 0u) + (e & 1023u)], pp.md);
 }
-__device__ __forceinline__ void ntt_geom16(double (&tw)[16], const double base, const double ratio) {   // base * ratio^i, depth 4
+__device__ __forceinline__ void ntt_geom16(double (&tw)[16], const double base, const double ratio, const NttMod md) {   // base * ratio^i, depth 4
     double pw = ratio;
     tw[0] = base;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
 #pragma unroll
-        for (int i = 0; i < (1 << b); ++i) tw[i + (1 << b)] = ntt_mul(tw[i], pw);
-        if (b < 3) pw = ntt_mul(pw, pw);
+        for (int i = 0; i < (1 << b); ++i) tw[i + (1 << b)] = ntt_mul(tw[i], pw, md);
+        if (b < 3) pw = ntt_mul(pw, pw, md);
     }
 }
 __host__ __device__ constexpr int ntt_brev3(int v) { return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1); }
 __host__ __device__ constexpr int ntt_brev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v >> 1) & 2) | ((v >> 3) & 1); }
 
-__global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uint32_t *__restrict__ data, const uint32_t *__restrict__ whatp) {
+__global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uint32_t *__restrict__ data) {
     extern __shared__ double ntt_mid_lds[];
     constexpr int LD = NTT_MID_LD;
     double *const buf = ntt_mid_lds, *const wf = buf + 128 * LD, *const wi = wf + 64;
@@ -328,24 +379,26 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
     const int n = __builtin_amdgcn_readfirstlane(t >> 7);        // 0 .. 7, the same for the 64 lanes of a wave
     const int sgl = blockIdx.y, k2 = blockIdx.x;
     const size_t M = (size_t)1 << pl.m;
+    const NttPrime &pp = pl.pr[blockIdx.z / pl.E];              // blockIdx.z = prime * E + ensemble
+    const NttMod md = pp.md;
     uint32_t *const slab = data + ((size_t)blockIdx.z * 2 + sgl) * M + (size_t)k2 * NTT_MID_WORDS;
-    const uint32_t *const wslab = whatp + (size_t)k2 * NTT_MID_WORDS;
-    const uint32_t *const t1f = pl.t1, *const t1i = pl.t1 + ((size_t)1 << (pl.a1 + pl.a2));
-    if (t < 128) (t < 64 ? wf : wi)[t & 63] = (double)pl.wr[(t >> 6) * 192 + (t & 63)];
+    const uint32_t *const wslab = pp.whatp + (size_t)k2 * NTT_MID_WORDS;
+    const uint32_t *const t1f = pp.t1, *const t1i = pp.t1 + ((size_t)1 << (pl.a1 + pl.a2));
+    if (t < 128) (t < 64 ? wf : wi)[t & 63] = (double)pp.wr[(t >> 6) * 192 + (t & 63)];
     double x[16];
     {   // load (word t + 1024 tt = (i1 = n + 8 tt, i0 = c)), twiddle 1 = w^(R0 i1 k2)
         uint32_t raw[16];
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) raw[tt] = slab[t + tt * 1024];
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul((double)raw[tt], (double)t1f[(size_t)(n + 8 * tt) * k2]);
+        for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul((double)raw[tt], (double)t1f[(size_t)(n + 8 * tt) * k2], md);
     }
     uint32_t wv[16];                                            // the table's spectrum at this thread's slots of the product: asked for now
 #pragma unroll
     for (int j = 0; j < 16; ++j) wv[j] = wslab[(16 * n + j) * 128 + c];
     __syncthreads();
     // forward over i1, pass 1 (rows n + 8 tt of column c) -- in the registers of the load
-    ntt_reg_levels<4, false>(x, wf, n, 3, 0);
+    ntt_reg_levels<4, false>(x, wf, n, 3, 0, md);
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) buf[(n + 8 * tt) * LD + c] = x[tt];
     __syncthreads();
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         double y[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) y[v] = buf[(8 * u + v) * LD + c];
-        ntt_reg_levels<3, true>(y, wf, 0, 0, 4);
+        ntt_reg_levels<3, true>(y, wf, 0, 0, 4, md);
 #pragma unroll
         for (int v = 0; v < 8; ++v) buf[(8 * u + v) * LD + c] = y[v];
     }
@@ -363,10 +416,10 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
     {   // forward over i0 of the i1-slot c (k1 = brev(c)), pass 1: i0 = n + 8 tt, twiddle 2 = w^(i0 q), q = k2 + R2 k1
         const unsigned q = (unsigned)k2 + ((unsigned)ntt_bitrev(c, 7) << pl.a2);
         double tw[16];
-        ntt_geom16(tw, ntt_tw2(pl, false, (unsigned)n * q), ntt_tw2(pl, false, 8u * q));
+        ntt_geom16(tw, ntt_tw2(pp, pl.m, false, (unsigned)n * q), ntt_tw2(pp, pl.m, false, 8u * q), md);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul(buf[c * LD + n + 8 * tt], tw[tt]);
-        ntt_reg_levels<4, false>(x, wf, n, 3, 0);
+        for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul(buf[c * LD + n + 8 * tt], tw[tt], md);
+        ntt_reg_levels<4, false>(x, wf, n, 3, 0, md);
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) buf[c * LD + n + 8 * tt] = x[tt];
     }
@@ -375,14 +428,14 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         double y0[8], y1[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) { y0[v] = buf[c * LD + 16 * n + v]; y1[v] = buf[c * LD + 16 * n + 8 + v]; }
-        ntt_reg_levels<3, true>(y0, wf, 0, 0, 4);
-        ntt_reg_levels<3, true>(y1, wf, 0, 0, 4);
+        ntt_reg_levels<3, true>(y0, wf, 0, 0, 4, md);
+        ntt_reg_levels<3, true>(y1, wf, 0, 0, 4, md);
         double y[16];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { y[v] = ntt_mul(y0[v], (double)wv[v]); y[8 + v] = ntt_mul(y1[v], (double)wv[8 + v]); }
+        for (int v = 0; v < 8; ++v) { y[v] = ntt_mul(y0[v], (double)wv[v], md); y[8 + v] = ntt_mul(y1[v], (double)wv[8 + v], md); }
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) x[tt] = y[ntt_brev4(tt)];                 // logical row n' + 8 tt sits in slot 16 n + brev4(tt)
-        ntt_reg_levels<4, false>(x, wi, ntt_brev3(n), 3, 0);
+        ntt_reg_levels<4, false>(x, wi, ntt_brev3(n), 3, 0, md);
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) buf[c * LD + 16 * n + ntt_brev4(tt)] = x[tt];
     }
@@ -393,7 +446,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         double y[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) y[v] = buf[c * LD + 16 * ntt_brev3(v) + ub];
-        ntt_reg_levels<3, true>(y, wi, 0, 0, 4);
+        ntt_reg_levels<3, true>(y, wi, 0, 0, 4, md);
 #pragma unroll
         for (int v = 0; v < 8; ++v) buf[c * LD + 16 * ntt_brev3(v) + ub] = y[v];
     }
@@ -401,10 +454,10 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
     {   // inverse over i1 at i0 = c, pass 1: logical rows k1 = n + 8 tt in slots 16 brev3(n) + brev4(tt); twiddle 2^-1 = w^(-c (k2 + R2 k1))
         const int nb = 16 * ntt_brev3(n);
         double tw[16];
-        ntt_geom16(tw, ntt_tw2(pl, true, (unsigned)c * ((unsigned)k2 + ((unsigned)n << pl.a2))), ntt_tw2(pl, true, (unsigned)c << (3 + pl.a2)));
+        ntt_geom16(tw, ntt_tw2(pp, pl.m, true, (unsigned)c * ((unsigned)k2 + ((unsigned)n << pl.a2))), ntt_tw2(pp, pl.m, true, (unsigned)c << (3 + pl.a2)), md);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul(buf[(nb + ntt_brev4(tt)) * LD + c], tw[tt]);
-        ntt_reg_levels<4, false>(x, wi, n, 3, 0);
+        for (int tt = 0; tt < 16; ++tt) x[tt] = ntt_mul(buf[(nb + ntt_brev4(tt)) * LD + c], tw[tt], md);
+        ntt_reg_levels<4, false>(x, wi, n, 3, 0, md);
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) buf[(nb + ntt_brev4(tt)) * LD + c] = x[tt];
     }
@@ -415,56 +468,56 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
         double y[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) y[v] = buf[(16 * ntt_brev3(v) + ub) * LD + c];
-        ntt_reg_levels<3, true>(y, wi, 0, 0, 4);
+        ntt_reg_levels<3, true>(y, wi, 0, 0, 4, md);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const int i1 = 16 * ntt_brev3(v) + ub;
-            slab[i1 * 128 + c] = (uint32_t)ntt_mul(y[v], (double)t1i[(size_t)i1 * k2]);
+            slab[i1 * 128 + c] = (uint32_t)ntt_mul(y[v], (double)t1i[(size_t)i1 * k2], md);
         }
     }
 }
 
 // launch of a strided sweep whose radix is only known at run time (the i2 sweep: 2^a2, a2 = 1 .. 7)
-template <int AXIS, bool INV>
-inline void ntt_launch_strided(int a, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, bool timed, const NttPlan &pl, uint32_t *data, int *csig, int2 *ws, int flag) {
-#define NTT_CASE(AA) case AA: if (timed) hipExtLaunchKernelGGL((ntt_strided<AXIS, INV, AA>), grid, block, 0, stream, e0, e1, 0, pl, data, csig, ws, flag); \
-                              else hipLaunchKernelGGL((ntt_strided<AXIS, INV, AA>), grid, block, 0, stream, pl, data, csig, ws, flag); break;
+template <int AXIS, bool INV, int NP>
+inline void ntt_launch_strided(int a, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, bool timed, const NttPlan &pl, uint32_t *data, int *csig, void *ws, int flag) {
+#define NTT_CASE(AA) case AA: if (timed) hipExtLaunchKernelGGL((ntt_strided<AXIS, INV, AA, NP>), grid, block, 0, stream, e0, e1, 0, pl, data, csig, ws, flag); \
+                              else hipLaunchKernelGGL((ntt_strided<AXIS, INV, AA, NP>), grid, block, 0, stream, pl, data, csig, ws, flag); break;
     switch (a) { NTT_CASE(1) NTT_CASE(2) NTT_CASE(3) NTT_CASE(4) NTT_CASE(5) NTT_CASE(6) NTT_CASE(7) default: break; }
 #undef NTT_CASE
 }
 
-// ---- host side: tables of a plan (everything mod P by 64-bit integer arithmetic)
+// ---- host side: tables of a plan for one prime (everything mod P by 64-bit integer arithmetic)
 struct NttTables { std::vector<uint32_t> wr, t1, t2hi, t2lo; };
 inline void ntt_split(int m, int &a0, int &a1, int &a2) { a0 = 7; a1 = std::min(7, m - 7); a2 = m - 7 - a1; }
-inline void ntt_build_tables(int m, NttTables &T) {
+inline void ntt_build_tables(int m, uint32_t P, uint32_t G, NttTables &T) {
     int a0, a1, a2;
     ntt_split(m, a0, a1, a2);
     const unsigned long long M = 1ull << m;
-    const uint32_t w = ntt_powmod(NTT_G, (NTT_P - 1ull) / M), wi = ntt_powmod(w, NTT_P - 2ull);
+    const uint32_t w = ntt_powmod(G, (P - 1ull) / M, P), wi = ntt_powmod(w, P - 2ull, P);
     T.wr.assign(2 * 192, 1u);
     for (int inv = 0; inv < 2; ++inv) {
         const uint32_t ww = inv ? wi : w;
         const int as[3] = {a0, a1, a2};
         for (int ax = 0; ax < 3; ++ax) {
-            const uint32_t wR = ntt_powmod(ww, M >> as[ax]);          // w_R = w^(M / R)
+            const uint32_t wR = ntt_powmod(ww, M >> as[ax], P);       // w_R = w^(M / R)
             uint32_t cur = 1u;
-            for (int j = 0; j < 64; ++j) { T.wr[(size_t)inv * 192 + ax * 64 + j] = cur; cur = ntt_mulmod_u64(cur, wR); }
+            for (int j = 0; j < 64; ++j) { T.wr[(size_t)inv * 192 + ax * 64 + j] = cur; cur = ntt_mulmod_u64(cur, wR, P); }
         }
     }
     const size_t n1 = (size_t)1 << (a1 + a2);
     T.t1.assign(2 * n1, 1u);
     for (int inv = 0; inv < 2; ++inv) {
-        const uint32_t step = ntt_powmod(inv ? wi : w, 1ull << a0);    // w^(R0)
+        const uint32_t step = ntt_powmod(inv ? wi : w, 1ull << a0, P);    // w^(R0)
         uint32_t cur = 1u;
-        for (size_t e = 0; e < n1; ++e) { T.t1[inv * n1 + e] = cur; cur = ntt_mulmod_u64(cur, step); }
+        for (size_t e = 0; e < n1; ++e) { T.t1[inv * n1 + e] = cur; cur = ntt_mulmod_u64(cur, step, P); }
     }
     const size_t nhi = std::max<size_t>(M >> 10, 1);
     T.t2hi.assign(2 * nhi, 1u); T.t2lo.assign(2 * 1024, 1u);
     for (int inv = 0; inv < 2; ++inv) {
-        const uint32_t ww = inv ? wi : w, step = ntt_powmod(ww, 1024ull);
+        const uint32_t ww = inv ? wi : w, step = ntt_powmod(ww, 1024ull, P);
         uint32_t cur = 1u;
-        for (size_t e = 0; e < nhi; ++e) { T.t2hi[inv * nhi + e] = cur; cur = ntt_mulmod_u64(cur, step); }
+        for (size_t e = 0; e < nhi; ++e) { T.t2hi[inv * nhi + e] = cur; cur = ntt_mulmod_u64(cur, step, P); }
         cur = 1u;
-        for (size_t e = 0; e < 1024; ++e) { T.t2lo[inv * 1024 + e] = cur; cur = ntt_mulmod_u64(cur, ww); }
+        for (size_t e = 0; e < 1024; ++e) { T.t2lo[inv * 1024 + e] = cur; cur = ntt_mulmod_u64(cur, ww, P); }
     }
 }

@@ -21,8 +21,10 @@ __host__ __device__ inline size_t td_lds_cells(int K) { return ((size_t)(TD_SITE
 __host__ __device__ inline size_t td_lds_bytes(int K) { return td_lds_cells(K) + (size_t)TD_SITES * K * 8 + ((size_t)TD_SITES * K + 15) / 16 * 16 + 16; }
 inline int td_tiles(int L) { return (L + TD_OWN - 1) / TD_OWN; }
 
-template <bool K1>
+// F32: {W, S} are int2 in units of 2^-q (32-bit field) / double2 (binary64 field: the ratio S / W is all a proposal needs of them)
+template <bool K1, bool F32>
 __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
+    using WS = typename TsField<F32>::ws_t;
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K;
     char *lds_c = reinterpret_cast<char *>(lds);
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
     const int own0 = tile * TD_OWN, own_n = min(TD_OWN, L - own0), nfr = own_n + 4;          // owned sites, valid frame positions
     const int x0 = own0 - 2;                                                                 // site of frame position 0
     const uint32_t *__restrict__ cell_e = a.cell_in + (size_t)e * L * K;
-    const int2 *__restrict__ ws_e = reinterpret_cast<const int2 *>(a.ws_in) + (size_t)e * L;
+    const WS *__restrict__ ws_e = reinterpret_cast<const WS *>(a.ws_in) + (size_t)e * L;
     auto frame_site = [&](int i) -> int {                      // site of frame position i (-1 .. nfr), or -1: beyond a wall / the valid frame
         if (i < -1 || i > nfr) return -1;
         const int s = x0 + i;
@@ -96,11 +98,11 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
         for (int j = t; j < n_part; j += FU_THREADS) {         // (two particles a lane and round, both requests out first: slower -- 81 VGPRs, five waves)
             const uint2 pc = plist[j];
             const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16), s = x0 + pos;
-            const int2 f = ws_e[(unsigned)s];
+            const WS f = ws_e[(unsigned)s];
             uint32_t x[4];
             philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
             const bool anch = a.anchor ? a.anchor[s] != 0 : false;
-            // S / W does not care about the unit (2^-q in the integer field)
+            // S / W does not care about the unit (2^-q in the integer field; the binary64 quotient of two integers times one power of two is that of the integers)
             propL[pos * K + k] = decide_proposal(M, anch, s, (pc.y & CELL_PLUS) ? 1 : -1, (pc.y & CELL_BOUND) != 0, clip_field((double)f.y, (double)f.x), beta,
                                                  occ_at(pos), occ_at(pos - 1), occ_at(pos + 1), x);
         }

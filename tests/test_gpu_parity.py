@@ -811,7 +811,7 @@ def _oracle_window_field(table, pos, spin, L, a, b):
     return W, S
 
 
-@pytest.mark.parametrize("method", ["lattice", "tiles"])
+@pytest.mark.parametrize("method", ["lattice", "tiles", "tiles_sweep"])
 def test_config5_scale_field_against_oracle_windows(capi, method):
     """BASELINE config 5 scale (N = 1e6, L = 2e6, 40 001-entry table beyond LDS) against the ORACLE, where the oracle can go:
     after 200 steps the incrementally kept W, S are compared bit for bit with the oracle's stencil formula on four windows
@@ -823,9 +823,17 @@ def test_config5_scale_field_against_oracle_windows(capi, method):
     rng = np.random.default_rng(12)
     pos = rng.choice(L, size=N, replace=False).astype(np.int32)
     spin = rng.choice(np.array([1, -1], np.int8), size=N)
-    h = make_handle(capi, par, N, dt=0.0125, seed=6, method=method)
+    # tiles: the binary64 field by the exact convolution modulo two primes (the default at this size); tiles_sweep: the windowed sweep
+    sweep, method = method == "tiles_sweep", method.split("_")[0]
+    if sweep:
+        os.environ["APS_NTT"] = "0"
+    try:
+        h = make_handle(capi, par, N, dt=0.0125, seed=6, method=method)
+    finally:
+        os.environ.pop("APS_NTT", None)
     try:
         assert h.method == method
+        assert h.ntt_info()["on"] == (method == "tiles" and not sweep)
         tab, q = h.table()
         otab, oq = so.build_table(par.sigma_grid, L, 1, False)
         assert q == oq and np.array_equal(tab, otab[:len(tab)]) and len(tab) == 40001
@@ -971,16 +979,18 @@ def test_fp32_windowed_sweep_dense_buckets(capi, periodic):
         h.close()
 
 
+@pytest.mark.parametrize("fp32", [True, False], ids=["i32", "f64"])
 @pytest.mark.parametrize("sigma,L,fused", [(0.02, 90000, "1"), (0.02, 90000, "0"), (0.004, 16000, "1"), (0.1, 120000, "1")],
                          ids=["m17", "m17_five_launches", "m14_two_sweeps", "m18_beyond_lds"])
-def test_fp32_field_update_by_exact_convolution(capi, sigma, L, fused):
+def test_fp32_field_update_by_exact_convolution(capi, sigma, L, fused, fp32):
     """csrc/ntt_conv.hpp: the step's deposits -> W, S of all sites by ONE number-theoretic convolution (mod 15 * 2^27 + 1, length
     2^m >= L + 2 reach, wall images entered as mirrored deposits) instead of the sweep -- exact integers, so state after every
     block and {W, S, occupancy} on ALL sites must equal the oracle's (which knows nothing of transforms) bit for bit.  Forced by
     APS_NTT=1 for tables that fit LDS (the first two cases: transforms of three and of two sweeps); the third is beyond LDS and
     takes the convolution by itself.  From m = 15 on the three middle launches are one (ntt_mid: a 128 x 128 slab per workgroup);
     APS_NTT_FUSED=0 keeps the five launches, which m = 14 always takes.  Dense clusters at both walls and inside, K = 3, a thin
-    background."""
+    background.  f64: the binary64 field (integers below 2^51 in units of its 2^-q) by the same transform modulo two primes, put
+    together by the last sweep (Chinese remainder) -- from m = 15 on (the binary64 table of the second case is longer: m = 15)."""
     par = params(L=L, K=3, sigma=sigma, rate_diffusion=3.0)
     rng = np.random.default_rng(2)
     sites = np.concatenate([rng.integers(L // 4, L // 4 + 1500, 2500), rng.integers(0, L, 1500), np.arange(L - 300, L), np.arange(0, 200)])
@@ -988,12 +998,12 @@ def test_fp32_field_update_by_exact_convolution(capi, sigma, L, fused):
     pos = rng.permutation(np.concatenate([np.repeat(x, min(k, 3)) for x, k in zip(u, c)])).astype(np.int32)
     spin = rng.choice(np.array([1, -1], np.int8), size=len(pos))
     N = len(pos)
-    orc = so.SyncOracle(par, dt=0.05, seed=7, sum_bits=29)
+    orc = so.SyncOracle(par, dt=0.05, seed=7, **(dict(sum_bits=29) if fp32 else {}))
     orc.set_state(pos, spin)
     os.environ["APS_NTT"] = "1"
     os.environ["APS_NTT_FUSED"] = fused
     try:
-        h = make_handle(capi, par, N, dt=0.05, seed=7, method="tiles", fp32=True)
+        h = make_handle(capi, par, N, dt=0.05, seed=7, method="tiles", fp32=fp32)
     finally:
         del os.environ["APS_NTT"], os.environ["APS_NTT_FUSED"]
     try:
