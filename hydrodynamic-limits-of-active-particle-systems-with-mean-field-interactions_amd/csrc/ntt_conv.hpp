@@ -178,52 +178,52 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
 #pragma unroll 1
     for (int q = 0; q < npr; ++q) {
         const int pi = (first || last) ? q : (int)blockIdx.z / pl.E;
-        const NttPrime &pp = pl.pr[pi];
+        const NttPrime pp = pi ? pl.pr[1] : pl.pr[0];            // (a select of scalars: indexing the argument would put the array into registers)
         const NttMod md = pp.md;
         uint32_t *sig0 = data + (((size_t)pi * pl.E + ens) * 2 + sgl) * M;
         if (q) __syncthreads();                                  // everyone has read the previous prime's result out of LDS
+        int tl = t;                                              // opaque per iteration: hoisted out of the loop, the 16 word addresses (and as many
+        if (NP > 1) asm volatile("" : "+v"(tl));                 // LDS offsets) of a thread would stay in registers across both transforms
         if (t < 64) wtab[t] = (double)pp.wr[(INV ? 192 : 0) + (AXIS == 2 ? 128 : 64) + t];
         // ---- load (row r = axis digit, column c): + twiddle of the i1 sweep going forward
         {
             uint32_t raw[NI], twv[NI];
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
-                const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+                const int w = tl + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
                 const size_t g = base + (size_t)r * stride + c;
                 raw[u] = first ? 0u : sig0[g];
                 twv[u] = (AXIS == 1 && !INV) ? pp.t1[(size_t)r * k2] : 1u;       // w^(R0 i1 k2), i1 = r
             }
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
-                const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+                const int w = tl + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
                 double v0 = first ? (double)coef[u] : (double)raw[u];            // (coefficients: small signed integers)
                 if (AXIS == 1 && !INV) v0 = ntt_mul(v0, (double)twv[u], md);
                 buf[r * ld + c] = v0;
             }
         }
         __syncthreads();
-        ntt_lds_transform<A>(buf, lg_nc, ld, wtab, t, md);
+        ntt_lds_transform<A>(buf, lg_nc, ld, wtab, tl, md);
         // ---- store, un-permuting the bit-reversed output: slot r gets the value of frequency r
         uint32_t twv[NI];
-        int old_w[NP == 1 ? NI : 1];                             // FINAL: the sites' W (or S) this thread will add to: int32 field
-        double old_d[NP > 1 ? NI : 1];                           // ... binary64 field
+        int old_w[NP == 1 ? NI : 1];                             // FINAL, int32 field: the sites' W (or S) this thread will add to (binary64: read where it is added)
         const bool combine = last && q == npr - 1;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
-            const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+            const int w = tl + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
             twv[u] = (AXIS == 1 && INV) ? pp.t1[((size_t)1 << (pl.a1 + pl.a2)) + (size_t)r * k2] : 1u;   // w^(-R0 i1 k2): the result index r is i1
-            if constexpr (NP == 1) old_w[u] = 0; else old_d[u] = 0.0;
-            if (combine) {
-                const long long site = (long long)(base + (size_t)r * stride + c) - pl.Rt;
-                if (site >= 0 && site < pl.L) {
-                    if constexpr (NP == 1) old_w[u] = reinterpret_cast<const int *>(reinterpret_cast<const int2 *>(ws) + (size_t)ens * pl.L + site)[sgl];
-                    else old_d[u] = reinterpret_cast<const double *>(reinterpret_cast<const double2 *>(ws) + (size_t)ens * pl.L + site)[sgl];
+            if constexpr (NP == 1) {
+                old_w[u] = 0;
+                if (combine) {
+                    const long long site = (long long)(base + (size_t)r * stride + c) - pl.Rt;
+                    if (site >= 0 && site < pl.L) old_w[u] = reinterpret_cast<const int *>(reinterpret_cast<const int2 *>(ws) + (size_t)ens * pl.L + site)[sgl];
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
-            const int w = t + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
+            const int w = tl + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
             double d0 = buf[ntt_bitrev(r, A) * ld + c];
             const size_t g = base + (size_t)r * stride + c;
             if (AXIS == 1 && INV) d0 = ntt_mul(d0, (double)twv[u], md);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
                 const uint32_t tt = ntt_canon((uint32_t)ntt_mul((double)dd, (double)pl.crt_inv, md), P1);
                 const unsigned long long x = (unsigned long long)r0 + (unsigned long long)P0 * tt, PP = (unsigned long long)P0 * P1;
                 const long long xs = x > PP / 2 ? (long long)(x - PP) : (long long)x;
-                if (xs) reinterpret_cast<double *>(reinterpret_cast<double2 *>(ws) + (size_t)ens * pl.L + site)[sgl] = old_d[u] + (double)xs * pl.unit;
+                if (xs) reinterpret_cast<double *>(reinterpret_cast<double2 *>(ws) + (size_t)ens * pl.L + site)[sgl] += (double)xs * pl.unit;   // (exact: both on the grid 2^-q)
             }
         }
     }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_contig(const NttPlan pl, uint
     constexpr int A0 = 7, R0 = 1 << A0, lg_nr = 12 - A0, NR = 1 << lg_nr;   // rows per tile
     const size_t M = (size_t)1 << pl.m;
     const size_t row0 = (size_t)blockIdx.x * NR;                 // row = (i1-slot, i2-slot) = k1 + R1 k2
-    const NttPrime &pp = pl.pr[blockIdx.z / pl.E];              // blockIdx.z = prime * E + ensemble: the signals are laid out in that order
+    const NttPrime pp = (int)blockIdx.z >= pl.E ? pl.pr[1] : pl.pr[0];              // blockIdx.z = prime * E + ensemble: the signals are laid out in that order
     const NttMod md = pp.md;
     uint32_t *sig0 = data + ((size_t)blockIdx.z * 2 + sgl) * M;
     constexpr int ld = NR + 1;                                   // element (transform row i0, tile row r) at i0 * ld + r
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NTT_MID_THREADS) void ntt_mid(const NttPlan pl, uin
     const int n = __builtin_amdgcn_readfirstlane(t >> 7);        // 0 .. 7, the same for the 64 lanes of a wave
     const int sgl = blockIdx.y, k2 = blockIdx.x;
     const size_t M = (size_t)1 << pl.m;
-    const NttPrime &pp = pl.pr[blockIdx.z / pl.E];              // blockIdx.z = prime * E + ensemble
+    const NttPrime pp = (int)blockIdx.z >= pl.E ? pl.pr[1] : pl.pr[0];              // blockIdx.z = prime * E + ensemble
     const NttMod md = pp.md;
     uint32_t *const slab = data + ((size_t)blockIdx.z * 2 + sgl) * M + (size_t)k2 * NTT_MID_WORDS;
     const uint32_t *const wslab = pp.whatp + (size_t)k2 * NTT_MID_WORDS;
