@@ -608,15 +608,19 @@ def main():
                                     for x, y in zip(before, [h.get_state(ensemble=e) for e in range(n_ens)])))
                 del before
             algo = {k: step_algo_bytes(k, N_all, L_all, w["K"], dep_per_step, bool(w.get("fp32")), changed) for k in kern}
-            if "tile_dense" in algo:                   # cell words read and written, {W, S} (two int32) at the particles' sites; the coefficient atomics left out
-                algo["tile_dense"] = 8.0 * w["K"] * L_all + 8.0 * N_all
+            if "tile_dense" in algo:                   # cell words read and written, {W, S} (int2 / double2) at the particles' sites; the coefficient atomics left out
+                algo["tile_dense"] = 8.0 * w["K"] * L_all + (8.0 if w.get("fp32") else 16.0) * N_all
             launches_per_step = {k: 1 for k in kern}
             if "ntt_conv" in kern:
-                # per launch: both signals of 2^m residues read and written (4 B each); per step on top: the deposit signals read
-                # by the first sweep, the table's spectrum by the middle one, {W, S} read and written by the last one
+                # per launch and prime: both signals of 2^m residues read and written (4 B each) -- the first sweep reads the deposit
+                # signals instead (once for all primes), the last one reads residues and reads + writes {W, S} of the sites (int2 / double2);
+                # per step on top: the table's spectrum, read by the middle launch
                 M_ntt = float(1 << ntt["log2_m"]) * n_ens
-                launches_per_step["ntt_conv"] = ntt["prof_launches"] / reps
-                algo["ntt_conv"] = (launches_per_step["ntt_conv"] * 16.0 * M_ntt + 8.0 * M_ntt + 4.0 * M_ntt + 16.0 * L_all) / launches_per_step["ntt_conv"]
+                n_pr = 1 if w.get("fp32") else 2                       # binary64 field: two primes
+                lps = ntt["prof_launches"] / reps
+                launches_per_step["ntt_conv"] = lps
+                algo["ntt_conv"] = (lps * 16.0 * M_ntt * n_pr - (n_pr - 1) * 8.0 * M_ntt - 8.0 * M_ntt * n_pr      # (the last sweep writes no residues)
+                                    + 4.0 * M_ntt * n_pr + (16.0 if w.get("fp32") else 32.0) * L_all) / lps
             step_bytes = sum(algo[k] * launches_per_step[k] for k in kern)
             if loop_steps > 0:
                 # the timed steps ran inside tile_loop: ONE launch = loop_steps steps; its duration from events attached to

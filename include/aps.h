@@ -251,10 +251,11 @@ int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps);
  * returns to the Curie-Weiss rate.  Rates must be finite and >= 0. */
 int aps_set_flip_table(aps_handle *h, const double *table, int32_t n);
 
-/* The field update as an exact convolution (csrc/ntt_conv.hpp): TILES handles with the 32-bit field, reflecting walls, one rank
- * and a weight table beyond LDS (BASELINE config 5) add a step's deposits to W, S by a number-theoretic transform of length
- * 2^log2_m >= L + 2 reach (mod P = 15 * 2^27 + 1: exact integers, same bits as the sweep) instead of gathering deposits x taps
- * table entries.  on: whether this handle does (APS_NTT=0 keeps the sweep, APS_NTT=1 takes the convolution for tables that fit
+/* The field update as an exact convolution (csrc/ntt_conv.hpp): TILES handles with reflecting walls, one rank and a weight
+ * table beyond LDS (BASELINE config 5) add a step's deposits to W, S by a number-theoretic transform of length
+ * 2^log2_m >= L + 2 reach instead of gathering deposits x taps table entries -- exact integers, same bits as the sweep: mod
+ * P0 = 15 * 2^27 + 1 for the 32-bit field (fp32), mod P0 and P1 = 27 * 2^26 + 1 with the Chinese remainder for the binary64 field.
+ * on: whether this handle does (APS_NTT=0 keeps the sweep, APS_NTT=1 takes the convolution for tables that fit
  * LDS as well); prof_ms / prof_launches: summed duration and number of the convolution's launches in the last aps_step_profile. */
 int aps_ntt_info(aps_handle *h, int32_t *on, int32_t *log2_m, double *prof_ms, int64_t *prof_launches);
 /* Launches per convolution: 3 when the transform has at least two 128 x 128 slabs (log2_m >= 15: sweep along the slab index, ONE

@@ -12,6 +12,8 @@ $b --steps 20 --warmup 5 --no-cpu-baseline > "$root/$out/bench_config2_driver_fo
 $b --workload config4 --steps 1000 --warmup 50 > "$root/$out/bench_config4.json" 2> "$root/$out/bench_config4.err"
 $b --workload config5 --steps 300 --warmup 20 > "$root/$out/bench_config5.json" 2> "$root/$out/bench_config5.err"
 APS_NTT=0 $b --workload config5 --steps 300 --warmup 20 > "$root/$out/bench_config5_sweep.json" 2>> "$root/$out/bench_config5.err"
+$b --workload config5 --f64 --steps 300 --warmup 20 > "$root/$out/bench_config5_f64.json" 2>> "$root/$out/bench_config5.err"
+APS_NTT=0 $b --workload config5 --f64 --steps 100 --warmup 10 > "$root/$out/bench_config5_f64_sweep.json" 2>> "$root/$out/bench_config5.err"
 $b --workload hbm --steps 100 --warmup 10 > "$root/$out/bench_hbm.json" 2> "$root/$out/bench_hbm.err"
 APS_BENCH_DEVICE=0 $b --gpus 2 --steps 200 --warmup 20 > "$root/$out/bench_config3_two_ranks_one_gpu.json" 2> "$root/$out/bench_two_ranks.err"
 echo "bench done"
