@@ -1937,7 +1937,7 @@ void ts_choose_geometry(aps_handle *h) {
     // the others (config 2: 512 tiles of 391 sites, 12.8 us per step against 13.3 with 633 tiles of 316; one launch per
     // step is indifferent: 14.65 against 14.55)
     int own_even = 0;
-    if (h->world == 1 && h->model.field_mode && 3 * h->p.K <= 32) {
+    if (h->world == 1 && h->model.field_mode && 3 * h->p.K <= 32 && !(h->p.K == 1 && h->model.immobilize && h->model.k_exit > 0.0)) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->p.device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
         const int64_t target = 2LL * cus / std::max(h->E, 1);
@@ -2219,6 +2219,9 @@ int loop_prepare(aps_handle *h) {
     if (h->ntt_on) return no("field updated by the exact convolution");
     if (!h->ts_table_in_lds) return no("weight table beyond LDS");
     if (!h->model.field_mode) return no("global mean field");
+    // K = 1: nothing ever binds (an anchor binds into free capacity next to the particle itself), so nothing leaves either -- unless
+    // the caller's state already holds bound particles; tile_loop's K = 1 path carries no exit code
+    if (h->p.K == 1 && h->model.immobilize && h->model.k_exit > 0.0) return no("particles can leave the system (one cell per site)");
     if (3 * h->p.K > 32) return no("site capacity above 10");
     if (h->p.L - (int64_t)(h->ts_ntile - 1) * h->ts_own < 3) return no("last tile shorter than three sites");
 #ifdef APS_STAMPS
