@@ -1985,7 +1985,7 @@ TileArgs tile_args(aps_handle *h, bool field_only) {
     TileArgs a{};
     const int par = (int)(h->step & 1), out = field_only ? par : par ^ 1;
     a.L = h->p.L; a.K = h->p.K; a.tlen = h->tlen; a.own = h->ts_own; a.ntile = h->ts_ntile; a.dcap = h->ts_dcap; a.par = par;
-    a.dense = h->ntt_on ? h->d_ntt_csig : nullptr; a.dense_rt = h->ntt.Rt; a.dense_m = h->ntt.m;
+    a.dense = h->ntt_on ? h->d_ntt_csig : nullptr; a.dense_rt = h->ntt.Rt; a.dense_m = h->ntt.m; a.periodic = h->p.periodic;
     a.tile_lo = h->ts_lo; a.field_only = field_only ? 1 : 0; a.field_mode = h->model.field_mode; a.ens_base = h->model.ens_base; a.E = h->E;
     a.seed_lo = h->model.seed_lo; a.seed_hi = h->model.seed_hi;
     a.model = h->d_model; a.rare = h->d_rare;
@@ -2092,10 +2092,12 @@ int ntt_setup(aps_handle *h) {
     const char *env = std::getenv("APS_NTT");
     if (env && env[0] == '0') return APS_OK;
     const bool forced = env && env[0] == '1';
-    if (!is_tiles(h) || !h->model.field_mode || h->p.periodic || h->world != 1) return APS_OK;
+    if (!is_tiles(h) || !h->model.field_mode || h->world != 1) return APS_OK;
     if (h->ts_table_in_lds && !forced) return APS_OK;           // the in-LDS sweep (and the resident loop) is faster for short tables
     const int Rt = h->tlen - 1, L = h->p.L;
-    if (!(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;   // one wall image per deposit at most
+    // one image per deposit at most: between walls the table must be short of half the box; on a torus (ring-wide table, Rt <= L / 2: a
+    // deposit within Rt of either end of [0, L) is entered a second time one period on) the box must be far longer than a frame of tile_dense
+    if (h->p.periodic ? !(2 * Rt <= L && L >= 4 * TD_SITES) : !(2 * Rt + 64 * h->ts_RS + h->ts_own + 4 < L)) return APS_OK;
     int m = 14;
     while (((int64_t)1 << m) < (int64_t)L + 2 * Rt) ++m;
     const int np = h->f32 ? 1 : 2;                              // the binary64 field: two primes, put together by the last sweep
@@ -2147,7 +2149,9 @@ int ntt_setup(aps_handle *h) {
             for (int t = 0; t < h->tlen; ++t) {
                 const uint32_t v = (uint32_t)((unsigned long long)std::ldexp(h->table[(size_t)t], h->q) % NTT_PRIMES[k]);
                 wext[(size_t)k * 2 * M + (size_t)t] = v;
-                if (t) wext[(size_t)k * 2 * M + M - (size_t)t] = v;
+                // (torus of even length: the tap at distance L / 2 counts once -- a site sees a deposit half a ring away either directly
+                //  or through its image; the kernel keeps +L / 2 and drops -L / 2)
+                if (t && !(h->p.periodic && 2 * t == L)) wext[(size_t)k * 2 * M + M - (size_t)t] = v;
             }
         HIP_TRY(h, hipMemcpyAsync(h->d_ntt_sig, wext.data(), wext.size() * 4, hipMemcpyHostToDevice, h->stream));
         const dim3 grid((unsigned)(M / NTT_TILE), 1u, (unsigned)np), block(NTT_THREADS);

@@ -37,9 +37,11 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
     const int x0 = own0 - 2;                                                                 // site of frame position 0
     const uint32_t *__restrict__ cell_e = a.cell_in + (size_t)e * L * K;
     const WS *__restrict__ ws_e = reinterpret_cast<const WS *>(a.ws_in) + (size_t)e * L;
+    const bool torus = a.periodic != 0;                        // (L is far longer than a frame then: ntt_setup)
     auto frame_site = [&](int i) -> int {                      // site of frame position i (-1 .. nfr), or -1: beyond a wall / the valid frame
         if (i < -1 || i > nfr) return -1;
-        const int s = x0 + i;
+        int s = x0 + i;
+        if (torus) { s = s < 0 ? s + L : (s >= L ? s - L : s); return s; }
         return (s < 0 || s >= L) ? -1 : s;
     };
     if (t == 0) misc[0] = 0;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
         const Model M = *a.model;                              // uniform address: scalar loads
         for (int j = t; j < n_part; j += FU_THREADS) {         // (two particles a lane and round, both requests out first: slower -- 81 VGPRs, five waves)
             const uint2 pc = plist[j];
-            const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16), s = x0 + pos;
+            const int pos = (int)(pc.x & 0xFFFFu), k = (int)(pc.x >> 16), s = frame_site(pos);
             const WS f = ws_e[(unsigned)s];
             uint32_t x[4];
             philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), pc.y & CELL_ID, (uint32_t)(a.ens_base + e), a.seed_lo, a.seed_hi, x);
@@ -123,11 +125,12 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
     uint32_t *cell_o = a.cell_out + (size_t)e * L * K;
     int *const cw_sig = a.dense + ((size_t)e << (a.dense_m + 1)), *const cs_sig = cw_sig + ((size_t)1 << a.dense_m);
     const int Rt = a.dense_rt;
-    auto emit = [&](const int s, const int cw, const int cs) {  // a field change at site s, wall image included
+    // a field change at site s, with its image: the mirror site beyond a wall (-1 - s, 2 L - 1 - s), or the same site one period on (s + L, s - L)
+    auto emit = [&](const int s, const int cw, const int cs) {
         const int at = s + Rt;
         if (cw) atomicAdd(cw_sig + at, cw);
         atomicAdd(cs_sig + at, cs);
-        const int img = s < Rt ? Rt - 1 - s : (s >= L - Rt ? 2 * L - 1 - s + Rt : -1);
+        const int img = s < Rt ? (torus ? at + L : Rt - 1 - s) : (s >= L - Rt ? (torus ? at - L : 2 * L - 1 - s + Rt) : -1);
         if (img >= 0) { if (cw) atomicAdd(cw_sig + img, cw); atomicAdd(cs_sig + img, cs); }
     };
     // the event of the particle `c` on site s: returns whether it is still on the site afterwards (c updated);
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
         const int sgn = (c & CELL_PLUS) ? 1 : -1;
         bool stays = true;
         if (ev == EV_LEFT || ev == EV_RIGHT || ev == EV_FWD) {
-            if (hop_granted) { stays = false; emit(s, -1, -sgn); emit(x0 + j, 1, sgn); }
+            if (hop_granted) { stays = false; emit(s, -1, -sgn); emit(frame_site(j), 1, sgn); }
         } else if (ev == EV_BIND) c |= CELL_BOUND;
         else if (ev == EV_UNBIND) c &= ~CELL_BOUND;
         else if (ev == EV_FLIP) { c ^= CELL_PLUS; emit(s, 0, -2 * sgn); }

@@ -30,7 +30,7 @@ struct TileRare { double *exit_log; unsigned *n_exit; uint32_t *src; const uint3
                   int rec_lo, rec_hi; };   // the rank's own tiles: exits in ghost tiles (stepped redundantly) are the owner's to record
 
 struct TileArgs {
-    int L, K, tlen, own, ntile, dcap, par, tile_lo, field_only, field_mode, ens_base, E;
+    int L, K, tlen, own, ntile, dcap, par, tile_lo, field_only, field_mode, ens_base, E, periodic;
     int dense_rt, dense_m;                             // tile_dense.hpp only: the deposits of the step go into the coefficient signals of the
     int *dense;                                        // convolution (ntt_conv.hpp) [E][2][2^dense_m], index = site + dense_rt, instead of lists
     uint32_t seed_lo, seed_hi;                         // Philox key

@@ -251,7 +251,7 @@ int aps_step_info(aps_handle *h, int64_t *graph_steps, int64_t *single_steps);
  * returns to the Curie-Weiss rate.  Rates must be finite and >= 0. */
 int aps_set_flip_table(aps_handle *h, const double *table, int32_t n);
 
-/* The field update as an exact convolution (csrc/ntt_conv.hpp): TILES handles with reflecting walls, one rank and a weight
+/* The field update as an exact convolution (csrc/ntt_conv.hpp): TILES handles (reflecting walls or torus) with one rank and a weight
  * table beyond LDS (BASELINE config 5) add a step's deposits to W, S by a number-theoretic transform of length
  * 2^log2_m >= L + 2 reach instead of gathering deposits x taps table entries -- exact integers, same bits as the sweep: mod
  * P0 = 15 * 2^27 + 1 for the 32-bit field (fp32), mod P0 and P1 = 27 * 2^26 + 1 with the Chinese remainder for the binary64 field.

@@ -1061,6 +1061,45 @@ def test_fp32_convolution_with_ensembles_anchors_and_exits(capi):
         h.close()
 
 
+@pytest.mark.parametrize("fp32", [True, False], ids=["i32", "f64"])
+@pytest.mark.parametrize("L,sigma", [(70000, 0.05), (65537, 0.3)], ids=["even_short_table", "odd_ring_wide_table"])
+def test_convolution_on_a_torus(capi, L, sigma, fp32):
+    """The convolution path with periodic boundaries, where the reference itself multiplies FFTs (PARTICLE_solver_CLASS.py:223-227):
+    a deposit within the table's reach of either end of [0, L) is entered a second time one period on (s + L, s - L), the tap at
+    distance L / 2 of an even ring counts once.  A table that ends before half the ring and one that spans it (odd L: every distance
+    up to (L - 1) / 2), K = 2, clusters across the seam; state and {W, S, occupancy} on all sites against the oracle, bit for bit."""
+    par = params(L=L, K=2, sigma=sigma, periodic=True, rate_diffusion=3.0)
+    rng = np.random.default_rng(4)
+    sites = np.concatenate([rng.integers(0, L, 3000), np.arange(L - 400, L), np.arange(0, 300), rng.integers(L // 2 - 500, L // 2 + 500, 1200)])
+    u, c = np.unique(sites, return_counts=True)
+    pos = rng.permutation(np.concatenate([np.repeat(x, min(k, 2)) for x, k in zip(u, c)])).astype(np.int32)
+    spin = rng.choice(np.array([1, -1], np.int8), size=len(pos))
+    N = len(pos)
+    orc = so.SyncOracle(par, dt=0.05, seed=17, **(dict(sum_bits=29) if fp32 else {}))
+    orc.set_state(pos, spin)
+    os.environ["APS_NTT"] = "1"
+    try:
+        h = make_handle(capi, par, N, dt=0.05, seed=17, method="tiles", fp32=fp32)
+    finally:
+        del os.environ["APS_NTT"]
+    try:
+        info = h.ntt_info()
+        assert info["on"] and info["launches"] == 3, info
+        if sigma > 0.2:
+            assert len(h.table()[0]) - 1 == L // 2                # ring-wide
+        h.set_state(pos, spin)
+        check_lattice(h, orc)
+        for block, n in enumerate((1, 2, 21)):
+            h.step(n)
+            orc.run(n)
+            p, sg, bd, al = h.get_state()
+            assert np.array_equal(p, orc.pos) and np.array_equal(sg, orc.spin), block
+            check_lattice(h, orc)
+        assert (p != pos).mean() > 0.4
+    finally:
+        h.close()
+
+
 def test_fp32_convolution_with_six_cells_per_site(capi):
     """csrc/tile_dense.hpp with K = 6: a frame's cells, particle list and proposals (80 KB) need the enlarged LDS limit; the general
     exclusion rule (rank among the proposers of a site against its free capacity) on crowded sites, bit for bit against the oracle."""
