@@ -16,6 +16,7 @@ $b --workload config5 --f64 --steps 300 --warmup 20 > "$root/$out/bench_config5_
 APS_NTT=0 $b --workload config5 --f64 --steps 100 --warmup 10 > "$root/$out/bench_config5_f64_sweep.json" 2>> "$root/$out/bench_config5.err"
 $b --workload hbm --steps 100 --warmup 10 > "$root/$out/bench_hbm.json" 2> "$root/$out/bench_hbm.err"
 APS_BENCH_DEVICE=0 $b --gpus 2 --steps 200 --warmup 20 > "$root/$out/bench_config3_two_ranks_one_gpu.json" 2> "$root/$out/bench_two_ranks.err"
+APS_BENCH_DEVICE=0 $b --gpus 2 --workload config5 --steps 60 --warmup 10 > "$root/$out/bench_config5_two_ranks_one_gpu.json" 2>> "$root/$out/bench_two_ranks.err"
 echo "bench done"
 # every tile_loop launch of this command takes 513 steps (warm-up, timed repeats, the timed-loop passes)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out/trace_config2" -o r03 -- python3 "$root/bench.py" --steps 513 --warmup 513 --no-cpu-baseline --repeats 2 > "$root/$out/trace_config2.log" 2>&1
