@@ -160,9 +160,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
     constexpr int ld = NC + 1;
     const int k2 = (int)outer;                                   // AXIS 1: the digit above (slot i2 holds k2)
     constexpr int NI = NTT_TILE / NTT_THREADS;                   // words per thread: all their loads are issued before the first is used
-    int coef[NI];                                                // INIT: the deposit coefficients, read once for all primes
+    int coef[NP > 1 ? NI : 1];                                   // INIT with two primes: the deposit coefficients, read once for both
     uint32_t res0[NP > 1 ? NI : 1];                              // FINAL with two primes: the residues mod the first one
-    if (first) {
+    if (NP > 1 && first) {
         int *c0 = csig + ((size_t)ens * 2 + sgl) * M;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
@@ -192,13 +192,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_strided(const NttPlan pl, uin
             for (int u = 0; u < NI; ++u) {
                 const int w = tl + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
                 const size_t g = base + (size_t)r * stride + c;
-                raw[u] = first ? 0u : sig0[g];
+                raw[u] = first ? (NP > 1 ? 0u : (uint32_t)csig[((size_t)ens * 2 + sgl) * M + g]) : sig0[g];
                 twv[u] = (AXIS == 1 && !INV) ? pp.t1[(size_t)r * k2] : 1u;       // w^(R0 i1 k2), i1 = r
             }
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
                 const int w = tl + u * NTT_THREADS, c = w & (NC - 1), r = w >> lg_nc;
-                double v0 = first ? (double)coef[u] : (double)raw[u];            // (coefficients: small signed integers)
+                double v0;
+                if (first) {                                     // deposit coefficients: small signed integers
+                    const int x0 = NP > 1 ? coef[u] : (int)raw[u];
+                    if (NP == 1 && x0) csig[((size_t)ens * 2 + sgl) * M + base + (size_t)r * stride + c] = 0;   // cleared for the next step
+                    v0 = (double)x0;
+                } else v0 = (double)raw[u];
                 if (AXIS == 1 && !INV) v0 = ntt_mul(v0, (double)twv[u], md);
                 buf[r * ld + c] = v0;
             }
