@@ -16,15 +16,17 @@
 // Reflecting walls: the deposits within the table's reach of a wall are entered a second time at their mirror site
 // (-1 - p, 2L - 1 - p), i.e. the signals live on [-Rt, L + Rt) and a plain linear convolution gives the reference's
 // mode='reflect' sums on [0, L); M >= L + 2 Rt makes the circular convolution equal to the linear one there.
+// Torus: the second entry is the same site one period on (p + L, p - L); the tap at distance L / 2 of an even ring counts once.
 //
 // Transform: M = R2 R1 R0 (R0 = 128 along memory, R1, R2 <= 128), index i = i0 + R0 i1 + R0 R1 i2, frequency
 // k = k2 + R2 k1 + R2 R1 k0:  w^(ik) = w_R2^(i2 k2) . w^(R0 i1 k2) . w_R1^(i1 k1) . w^(i0 (k2 + R2 k1)) . w_R0^(i0 k0)
 // -- three sweeps of small transforms held in LDS (one launch each: along i2, along i1, along i0) with two twiddle
 // multiplications in between; in place, slot i_a ends up holding k_a.  The last forward sweep, the product with the table's
 // spectrum and the first inverse sweep touch the same 128 contiguous words and are one kernel: five launches per convolution,
-// both signals in every launch.  Arithmetic: residues in [0, P) as uint32 in memory and LDS, products by binary64 fma (exact:
-// the error term of a * b and the quotient estimate both come from fma; full rate on CDNA, where 32-bit integer multiplies
-// run at a quarter).
+// both signals in every launch -- and from two 128 x 128 slabs on (m >= 15) everything between the two i2 sweeps is ONE launch
+// (ntt_mid: a slab per workgroup, in LDS): three.  Arithmetic: residues as uint32 in memory, as doubles in registers and LDS,
+// products by binary64 fma (exact: the error term of a * b and the quotient estimate both come from fma; full rate on CDNA,
+// where 32-bit integer multiplies run at a quarter).
 #pragma once
 
 constexpr uint32_t NTT_PRIMES[2] = {2013265921u, 1811939329u};   // 15 * 2^27 + 1, 27 * 2^26 + 1
