@@ -22,8 +22,13 @@ __host__ __device__ inline size_t td_lds_bytes(int K) { return td_lds_cells(K) +
 inline int td_tiles(int L) { return (L + TD_OWN - 1) / TD_OWN; }
 
 // F32: {W, S} are int2 in units of 2^-q (32-bit field) / double2 (binary64 field: the ratio S / W is all a proposal needs of them)
+#ifdef APS_TD_WAVES                        /* tuning builds: pin the waves per SIMD the register allocator aims for */
+#define TD_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(APS_TD_WAVES, APS_TD_WAVES)))
+#else
+#define TD_WAVES_ATTR
+#endif
 template <bool K1, bool F32>
-__global__ __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
+__global__ TD_WAVES_ATTR __launch_bounds__(FU_THREADS) void tile_dense(const TileArgs a) {
     using WS = typename TsField<F32>::ws_t;
     extern __shared__ double lds[];
     const int L = a.L, K = K1 ? 1 : a.K;
